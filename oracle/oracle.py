@@ -1,0 +1,188 @@
+"""ctypes/numpy front-end of oracle/libog_oracle.so (C restatement, og_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of og_oracle.c.  Parity status:
+pinned against the imported reference by tools/gen_golden.py and against
+tests/golden/*.npz by tests/test_oracle_golden.py.
+
+The wrappers mirror the reference call sequence of
+decoder/factory.py:52-96 (PostProcess.generate_poses) so that a test reads
+like the reference's own pipeline.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libog_oracle.so")
+
+__all__ = [
+    "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
+    "greedy_group", "group_stats", "flip_merge", "decode",
+]
+
+_lib = None
+_F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_I64 = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_I32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "og_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libog_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.ogo_bicubic4.argtypes = [_F, C.c_long, C.c_int, C.c_int, _F]
+        L.ogo_bilinear4.argtypes = [_F, C.c_long, C.c_int, C.c_int, _F]
+        L.ogo_hmp_nms.argtypes = [_F, C.c_long, C.c_int, C.c_int, _F]
+        L.ogo_topk.argtypes = [_F, C.c_long, C.c_long, C.c_int, _F, _I64]
+        L.ogo_topk.restype = C.c_int
+        L.ogo_nms_topk.argtypes = [_F, C.c_long, C.c_int, C.c_int, C.c_int, _F, _I64]
+        L.ogo_nms_topk.restype = C.c_int
+        L.ogo_collect_limbs.argtypes = [_F, _I64, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F]
+        L.ogo_greedy_group.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_double, C.c_float,
+                                       C.c_int, C.c_int, C.c_int, _F]
+        L.ogo_greedy_group.restype = C.c_int
+        L.ogo_flip_merge.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     _I32, _I32, _I32, C.c_int, _F, _F]
+        L.ogo_group_stats.argtypes = [np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), C.c_int]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def bicubic4(x):
+    """x4 bicubic upsample of (..., h, w) -- decoder/factory.py:74-75."""
+    x = _f32(x)
+    h, w = x.shape[-2:]
+    out = np.empty(x.shape[:-2] + (4 * h, 4 * w), np.float32)
+    lib().ogo_bicubic4(x, x.size // (h * w), h, w, out)
+    return out
+
+
+def bilinear4(x):
+    """x4 bilinear upsample of (..., h, w) -- decoder/factory.py:77-78."""
+    x = _f32(x)
+    h, w = x.shape[-2:]
+    out = np.empty(x.shape[:-2] + (4 * h, 4 * w), np.float32)
+    lib().ogo_bilinear4(x, x.size // (h * w), h, w, out)
+    return out
+
+
+def hmp_nms(x):
+    """decoder/heatmap.py:15-35."""
+    x = _f32(x)
+    H, W = x.shape[-2:]
+    out = np.empty_like(x)
+    lib().ogo_hmp_nms(x, x.size // (H * W), H, W, out)
+    return out
+
+
+def topk(scores, k):
+    """decoder/heatmap.py:38-49 -> (scores, inds, ys, xs) with floor-division ys."""
+    s = _f32(scores)
+    n, c, h, w = s.shape
+    os_ = np.empty((n, c, k), np.float32)
+    oi = np.empty((n, c, k), np.int64)
+    if lib().ogo_topk(s, n * c, h * w, k, os_, oi) != 0:
+        raise RuntimeError("k out of range")
+    return os_, oi, oi // w, oi % w
+
+
+def nms_topk(hm, k):
+    """decoder/heatmap.py:52-59 (joint_dets)."""
+    s = _f32(hm)
+    n, c, h, w = s.shape
+    os_ = np.empty((n, c, k), np.float32)
+    oi = np.empty((n, c, k), np.int64)
+    if lib().ogo_nms_topk(s, n * c, h, w, k, os_, oi) != 0:
+        raise RuntimeError("k out of range")
+    return os_, oi, oi // w, oi % w
+
+
+def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0):
+    """decoder/collect.py:62-236; `offs` low-res (bilinear-sampled) or hi-res (gathered)."""
+    scores = _f32(scores)
+    inds = np.ascontiguousarray(inds, dtype=np.int64)
+    offs = _f32(offs)
+    n, c, k = scores.shape
+    H, W = hw_shape
+    jf = np.array([a for a, _ in skeleton], np.int32)
+    jt = np.array([b for _, b in skeleton], np.int32)
+    L = len(skeleton)
+    limbs = np.empty((n, L, k, 13), np.float32)
+    lib().ogo_collect_limbs(scores, inds, offs, int(bool(off_lowres)), n, c, H, W, jf, jt, L, k,
+                            thre, min_len, resize, limbs)
+    return limbs
+
+
+def greedy_group(limbs, skeleton, n_keypoints, person_thre, dist_max, use_scale=False, sort_dim=2, mmax=None):
+    """decoder/group.py:39-185 for one image: (L,K,13) -> (M,17,6)."""
+    limbs = _f32(limbs)
+    L, K, _ = limbs.shape
+    assert L == len(skeleton), 'check the skeleton config and input limbs Tensor'
+    jf = np.array([a for a, _ in skeleton], np.int32)
+    jt = np.array([b for _, b in skeleton], np.int32)
+    mmax = mmax or L * K
+    poses = np.zeros((mmax, n_keypoints, 6), np.float32)
+    m = lib().ogo_greedy_group(limbs, L, K, jf, jt, n_keypoints, float(person_thre), float(dist_max),
+                               int(bool(use_scale)), int(sort_dim), mmax, poses)
+    if m < 0:
+        raise RuntimeError("mmax too small")
+    return poses[:m].copy()
+
+
+def group_stats(reset=False):
+    """Coverage counters of greedy_group since the last reset (see og_oracle.c)."""
+    out = np.zeros(9, np.int64)
+    lib().ogo_group_stats(out, int(reset))
+    names = ["phaseA", "phaseB", "phaseB_dup_row", "merges", "cross3", "nonreplaced_reset", "dup_a_merge",
+             "merged_row_deleted", "zero_sum_column"]
+    return dict(zip(names, out.tolist()))
+
+
+def flip_merge(hm, off, kp_perm, limb_perm, reserve):
+    """decoder/factory.py:98-146 (vector-addition form)."""
+    hm, off = _f32(hm), _f32(off)
+    n2, c, h, w = hm.shape
+    L = off.shape[1] // 2
+    n = n2 // 2
+    ho = np.empty((n, c, h, w), np.float32)
+    oo = np.empty((n, 2 * L, h, w), np.float32)
+    res = np.array(reserve, np.int32)
+    lib().ogo_flip_merge(hm, off, n, c, L, h, w, np.array(kp_perm, np.int32), np.array(limb_perm, np.int32),
+                         res if len(res) else np.zeros(1, np.int32), len(reserve), ho, oo)
+    return ho, oo
+
+
+def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,
+           dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False):
+    """PostProcess.generate_poses (decoder/factory.py:52-96) on low-res head outputs.
+
+    flip = (kp_perm, limb_perm, reserve) enables the flip-test merge first.
+    Returns (poses list, dict of intermediates).
+    """
+    if flip is not None:
+        hm_lr, off_lr = flip_merge(hm_lr, off_lr, *flip)
+    hm_hr = bicubic4(hm_lr)
+    n, c, H, W = hm_hr.shape
+    sc, idx, _, _ = nms_topk(hm_hr, topk_k)
+    if materialize_offsets:
+        limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len)
+    else:
+        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len)
+    poses = [greedy_group(limbs[i], skeleton, c, person_thre, dist_max, use_scale, sort_dim) for i in range(n)]
+    return poses, {"hm_hr": hm_hr, "scores": sc, "inds": idx, "limbs": limbs}

@@ -1,0 +1,63 @@
+"""Shared parity helpers (oracle side = checker only)."""
+import hashlib
+import os
+
+import numpy as np
+
+from offsetguided_amd import synth
+from offsetguided_amd.config.coco_data import (COCO_KEYPOINTS, COCO_PERSON_SKELETON, heatmap_hflip,
+                                               offset_hflip)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FLAGS = dict(topk=32, thre_hmp=0.04, person_thre=0.04, dist_max=40.0, min_len=0.5)
+PIPE_CASES = ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe256_flip_p20",
+              "pipe640", "pipe640_flip"]
+EXACT_LIMB_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12]
+EXACT_POSE_COLS = [0, 1, 2, 3, 5]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def flip_tables(skeleton=COCO_PERSON_SKELETON):
+    perm, rev = offset_hflip(COCO_KEYPOINTS, skeleton)
+    return heatmap_hflip(COCO_KEYPOINTS), perm, rev
+
+
+def load_case(name):
+    """Golden case + regenerated inputs (sha-guarded against generator drift)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_persons = int(g["n_persons"])
+    hm, off = synth.synth_batch(int(g["seed"]), int(g["batch"]), int(g["size"]), int(g["size"]),
+                                flip=bool(g["flip"]), n_persons=None if n_persons < 0 else n_persons)
+    assert [sha(hm), sha(off)] == list(g["in_sha"]), "synthetic input generator drifted (not a parity failure)"
+    return g, hm, off
+
+
+def split_poses(g):
+    out, o = [], 0
+    for n in g["n_poses"]:
+        out.append(g["poses"][o:o + n])
+        o += n
+    return out
+
+
+def assert_limbs_match(ref, got, tol=1e-4, valid_only_thre=None):
+    """Indices / coordinates / dist / len bit-exact, limb score within tol."""
+    ref, got = np.asarray(ref), np.asarray(got)
+    assert ref.shape == got.shape
+    if valid_only_thre is not None:  # rows with a sub-threshold endpoint are don't-care
+        ok = (ref[..., 2] >= valid_only_thre) & (ref[..., 5] >= valid_only_thre)
+        ref, got = ref[ok], got[ok]
+    assert (ref[..., EXACT_LIMB_COLS] == got[..., EXACT_LIMB_COLS]).all()
+    assert np.abs(ref[..., 10] - got[..., 10]).max(initial=0.0) <= tol
+
+
+def assert_poses_match(ref_list, got_list, tol=1e-4):
+    assert len(ref_list) == len(got_list)
+    for r, m in zip(ref_list, got_list):
+        assert r.shape == m.shape, f"pose count {r.shape} vs {m.shape}"
+        if r.size:
+            assert (r[..., EXACT_POSE_COLS] == m[..., EXACT_POSE_COLS]).all()
+            assert np.abs(r[..., 4] - m[..., 4]).max() <= tol

@@ -1,0 +1,73 @@
+"""The CPU oracle against the committed golden vectors (generated from the imported reference
+by tools/gen_golden.py).  CPU-only; pins the checker that the GPU parity tests rely on."""
+import numpy as np
+import pytest
+
+import oracle
+from offsetguided_amd import synth
+from offsetguided_amd.config import coco_data as cd
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, load_case,
+                     sha, split_poses)
+
+
+def test_stage_units():
+    g = np.load(f"{GOLDEN}/stage_units.npz")
+    x = synth.noise_batch(11, (2, 3, 24, 40))
+    z = synth.noise_batch(12, (2, 3, 37, 53))
+    assert [sha(x), sha(z)] == list(g["in_sha"])
+    assert sha(oracle.bicubic4(x)) == str(g["bicubic_sha"])
+    assert sha(oracle.bilinear4(x)) == str(g["bilinear_sha"])
+    assert sha(oracle.hmp_nms(z)) == str(g["nms_sha"])
+    s, i, ys, xs = oracle.topk(z, 9)
+    assert (s == g["topk_scores"]).all() and (i == g["topk_inds"]).all()
+    assert (ys == i // 53).all() and (xs == i % 53).all()
+
+
+@pytest.mark.parametrize("name", PIPE_CASES)
+def test_pipeline_case(name):
+    g, hm, off = load_case(name)
+    flip = flip_tables() if int(g["flip"]) else None
+    if flip:
+        mh, mo = oracle.flip_merge(hm, off, *flip)
+        assert [sha(mh), sha(mo)] == list(g["merged_sha"])
+    poses, mid = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                               min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"],
+                               dist_max=FLAGS["dist_max"], flip=flip)
+    assert sha(mid["hm_hr"]) == str(g["hm_hr_sha"])
+    assert (mid["scores"] == g["scores"]).all() and (mid["inds"] == g["inds"]).all()
+    assert_limbs_match(g["limbs"], mid["limbs"])
+    assert_poses_match(split_poses(g), poses)
+    # materialised x4 bilinear offsets + plain gather give the same limbs (decoder/factory.py:77-78)
+    merged_off = oracle.flip_merge(hm, off, *flip)[1] if flip else off
+    ohr = oracle.bilinear4(merged_off)
+    assert sha(ohr) == str(g["off_hr_sha"])
+    l2 = oracle.collect_limbs(mid["scores"], mid["inds"], ohr, False, mid["hm_hr"].shape[-2:],
+                              cd.COCO_PERSON_SKELETON, FLAGS["thre_hmp"], FLAGS["min_len"])
+    assert (l2 == mid["limbs"]).all()
+
+
+def test_grouping_adversarial():
+    g = np.load(f"{GOLDEN}/grouping_adversarial.npz")
+    oracle.group_stats(True)
+    for si, sk_name in enumerate(g["skeleton_names"]):
+        sk = getattr(cd, str(sk_name))
+        o = 0
+        for limbs, (K, M), cfg in zip(g[f"limbs_{si}"], g[f"kn_{si}"], g[f"cfg_{si}"]):
+            thre, dmax, use_scale, sort_dim = g["cfg_table"][cfg]
+            got = oracle.greedy_group(limbs[:, :K], sk, 17, thre, dmax, bool(use_scale), int(sort_dim))
+            ref = g[f"poses_{si}"][o:o + M]
+            o += M
+            assert got.shape == ref.shape and (got == ref).all()
+    st = oracle.group_stats()
+    # the stored cases exercise every branch of the grouping restatement
+    for k in ("phaseA", "phaseB", "phaseB_dup_row", "merges", "cross3", "dup_a_merge", "merged_row_deleted"):
+        assert st[k] > 0, k
+
+
+def test_topk_tie_rule_and_errors():
+    z = np.zeros((1, 1, 4, 5), np.float32)
+    z[0, 0, 2, 3] = 1.0
+    s, i, _, _ = oracle.nms_topk(z, 4)
+    assert i.tolist() == [[[13, 0, 1, 2]]] and s.tolist() == [[[1.0, 0.0, 0.0, 0.0]]]
+    with pytest.raises(RuntimeError):
+        oracle.topk(z, 21)
