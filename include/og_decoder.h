@@ -1,0 +1,117 @@
+/*
+ * og_decoder.h -- C ABI of libog_decoder.so: the OffsetGuided decoder hot path as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (hellojialee/OffsetGuided) is pure Python: it has no native boundary of
+ * its own.  Each entry point below replaces the torch-op sequence of one reference
+ * function (file:line given per function, relative to the reference repository root); the
+ * Python package offsetguided_amd.decoder binds them with ctypes behind the reference's own
+ * names (hmp_NMS, topK_channel, joint_dets, LimbsCollect, GreedyGroup, PostProcess).
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to dense, contiguous fp32 / int64 / int32 data
+ *     in the reference's NCHW layout; nothing is copied or retained;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     stream-ordered, asynchronous, and performs no allocation and no host synchronisation
+ *     (hipGraph-capturable); scratch comes from the caller through `workspace`;
+ *   - return value: 0 on success, negative OG_E* code on failure; og_last_error() returns a
+ *     thread-local message for the last failure on the calling thread; nothing throws;
+ *   - inputs must be finite (NaN ordering of torch.topk is not reproduced);
+ *   - no CPU fallback exists: without a HIP device every compute entry point fails.
+ */
+#ifndef OG_DECODER_H
+#define OG_DECODER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OG_ABI_VERSION 1
+
+#define OG_OK 0
+#define OG_EINVAL (-1)    /* bad argument (shape, k, alignment, null pointer)        */
+#define OG_ENOSPC (-2)    /* workspace too small                                     */
+#define OG_EHIP (-3)      /* HIP runtime error (launch failure, no device)           */
+#define OG_EUNSUPPORTED (-4)
+
+int og_abi_version(void);
+const char *og_last_error(void);
+
+/* Number of HIP devices visible, or a negative OG_E* code. */
+int og_device_count(void);
+
+/* ---- a5: F.interpolate(hmps, scale_factor=4, mode='bicubic')  decoder/factory.py:74-75 ----
+ * src (planes,h,w) -> dst (planes,4h,4w); torch-CPU fp32 arithmetic, bit-exact (A=-0.75,
+ * align_corners=False, index-clamped taps). */
+int og_upsample_bicubic4_f32(const float *src, long planes, int h, int w, float *dst, void *stream);
+
+/* ---- a5: F.interpolate(offs, scale_factor=4, mode='bilinear')  decoder/factory.py:77-78 ----
+ * Full materialisation; the decode path does not need it (og_collect_limbs_f32 samples the
+ * low-res map at the peaks with the same arithmetic). */
+int og_upsample_bilinear4_f32(const float *src, long planes, int h, int w, float *dst, void *stream);
+
+/* ---- a6: hmp_NMS  decoder/heatmap.py:15-35 ----
+ * out = heat * (maxpool3x3(zero-padded heat) == heat); heat/out (planes,H,W). */
+int og_hmp_nms_f32(const float *heat, long planes, int H, int W, float *out, void *stream);
+
+/* ---- a7: topK_channel  decoder/heatmap.py:38-49 ----
+ * Per-plane top-k of `scores` (planes, hw), sorted by value descending; ties: lower flat
+ * index first (-0.0 == +0.0).  Outputs scores (planes,k) f32 and inds (planes,k) i64; the
+ * caller derives ys = inds / w (floor) and xs = inds % w.
+ * workspace: og_topk_workspace_bytes(planes, H, W, k). */
+int og_topk_channel_f32(const float *scores, long planes, int H, int W, int k, float *out_scores,
+                        int64_t *out_inds, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a8: joint_dets = topK_channel(hmp_NMS(hmps), k)  decoder/heatmap.py:52-59 ----
+ * Fused single pass over the hi-res heatmaps: the NMS map is never written.  Same outputs
+ * and tie rule as og_topk_channel_f32 applied to og_hmp_nms_f32's result (zero-valued filler
+ * entries, if a plane has fewer than k positive peaks, are the lowest flat indices whose NMS
+ * value is zero).  Requires 2*(H+W)-4 >= k.
+ * workspace: og_topk_workspace_bytes(planes, H, W, k). */
+int og_nms_topk_f32(const float *hmps, long planes, int H, int W, int k, float *out_scores,
+                    int64_t *out_inds, void *workspace, size_t workspace_bytes, void *stream);
+
+size_t og_topk_workspace_bytes(long planes, int H, int W, int k);
+
+/* ---- a9+a10: LimbsCollect.generate_limbs  decoder/collect.py:62-236 (+ _channel_dets :246-254) ----
+ * scores/inds : (N,C,k) from og_nms_topk_f32 on (N,C,H,W) hi-res heatmaps
+ * offs        : off_is_lowres ? (N,2L,H/4,W/4) stride-4 head output, bilinearly sampled at the
+ *               from-peaks exactly as factory.py:77-78 + collect.py:143-147 would
+ *             : (N,2L,H,W) hi-res offsets, gathered
+ * jf/jt       : device int32[L] from/to joint channel per limb (LimbsCollect.pack_jtypes)
+ * limbs       : (N,L,k,13) [x1,y1,v1,x2,y2,v2,ind1,ind2,min_dist,len,score,scale1,scale2]
+ * No scale / jitter heads (scales are the constant 4, collect.py:117-122). */
+int og_collect_limbs_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                         int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                         float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
+
+/* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
+ * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,
+ * decoder/factory.py:91-94).
+ * limbs (N,L,k,13) -> poses (N,mmax,n_kp,6) [x,y,v,scale,limb_score,global_idx],
+ * counts int32[N] = poses per image, status int32[N] = 0 ok / 1 subset table overflowed
+ * (more than `mmax` partial skeletons alive; results for that image are then invalid).
+ * workspace: og_group_workspace_bytes(N, n_kp, mmax). */
+int og_greedy_group_f32(const float *limbs, int N, int L, int k, const int32_t *jf, const int32_t *jt,
+                        int n_kp, double person_thre, float dist_max, int use_scale, int sort_dim, int mmax,
+                        float *poses, int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+size_t og_group_workspace_bytes(int N, int n_kp, int mmax);
+
+/* ---- a4: PostProcess.flip_augment (vector-addition form)  decoder/factory.py:98-146 ----
+ * hm (2N,C,h,w), off (2N,2L,h,w) -> hm_out (N,C,h,w), off_out (N,2L,h,w).
+ * kp_perm int32[C], limb_perm int32[L], reserve_mask int32[L] (1 = keep the un-averaged
+ * original, config.offset_hflip()[1]) are device arrays. */
+int og_flip_merge_f32(const float *hm, const float *off, int N, int C, int L, int h, int w,
+                      const int32_t *kp_perm, const int32_t *limb_perm, const int32_t *reserve_mask,
+                      float *hm_out, float *off_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OG_DECODER_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of libog_decoder.so (include/og_decoder.h) + torch plumbing.
+
+There is NO fallback: if the shared library is missing or a tensor is not on a HIP device the
+call raises.  PyTorch is used only for device memory, streams and (elsewhere) the dense conv
+backbone; every decoder stage below is a hand-written HIP kernel.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libog_decoder.so")
+
+OG_OK, OG_EINVAL, OG_ENOSPC, OG_EHIP, OG_EUNSUPPORTED = 0, -1, -2, -3, -4
+ABI_VERSION = 1
+
+_vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/og_decoder.h one to one
+SIGNATURES = {
+    "og_abi_version": (_i, []),
+    "og_last_error": (C.c_char_p, []),
+    "og_device_count": (_i, []),
+    "og_upsample_bicubic4_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
+    "og_upsample_bilinear4_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
+    "og_hmp_nms_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
+    "og_topk_channel_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "og_nms_topk_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "og_topk_workspace_bytes": (_sz, [_l, _i, _i, _i]),
+    "og_collect_limbs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
+    "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
+    "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class OgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the C ABI.  Raises if the library is absent -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m offsetguided_amd.build` "
+                "(hipcc --offload-arch=gfx950).  offsetguided_amd has no CPU/torch fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.og_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.og_abi_version()} != {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc, lib=None):
+    if rc != OG_OK:
+        msg = (lib or load()).og_last_error().decode(errors="replace")
+        raise OgError(f"libog_decoder: {msg} (code {rc})")
+
+
+def require_device(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise OgError(f"{name}: tensor is on {t.device}; the HIP decoder kernels need a GPU tensor "
+                      "(offsetguided_amd has no CPU path)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes, tag="ws"):
+    """Per-(device, stream, tag) scratch buffer, grown geometrically, never shrunk."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+_const_cache = {}
+
+
+def int_table(values, device):
+    """Small int32 device table (skeleton / permutation), cached per device."""
+    key = (tuple(int(v) for v in values), device.index)
+    t = _const_cache.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=torch.int32, device=device)
+        _const_cache[key] = t
+    return t

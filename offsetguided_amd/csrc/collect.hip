@@ -1,0 +1,124 @@
+// K2 -- LimbsCollect.generate_limbs (decoder/collect.py:62-236, _channel_dets :246-254).
+//
+// One wave per (image, limb type).  The k to-candidates of the limb's end joint are staged in
+// LDS; lane i takes from-candidate i, reads its guiding offset (either gathered from hi-res
+// offset maps, or bilinearly sampled from the stride-4 head output with the arithmetic of
+// F.interpolate(x4, 'bilinear') so the 498 MB hi-res offset tensor is never built), scans the
+// to-candidates for the first nearest one and writes its 13-float limb row.  KB-sized,
+// latency-bound: ~40 torch launches in the reference, one here.
+//
+// fp32 arithmetic follows torch-CPU exactly where it decides an index:
+//   dist = sqrtf(fma(dy,dy, fl(dx*dx)))   (torch.norm over 2 elements)
+//   first minimum wins (torch.min tie rule on CPU)
+// exp() is the device libm (<= 1 ulp from torch's), so limb scores agree to ~1e-7 relative.
+#include <math.h>
+
+#include "og_common.h"
+
+namespace {
+
+__device__ __forceinline__ void lin_coord(int dpos, int n, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = 0.25f * ((float)dpos + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = (i0 + 1 < n) ? i0 + 1 : n - 1;
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__device__ __forceinline__ float bilinear4_at(const float *__restrict__ p, int h, int w, int Y, int X)
+{
+    int x0, x1, y0, y1;
+    float lx0, lx1, ly0, ly1;
+    lin_coord(X, w, x0, x1, lx0, lx1);
+    lin_coord(Y, h, y0, y1, ly0, ly1);
+    const float a = __builtin_fmaf(p[(size_t)y0 * w + x0], lx0, p[(size_t)y0 * w + x1] * lx1);
+    const float b = __builtin_fmaf(p[(size_t)y1 * w + x0], lx0, p[(size_t)y1 * w + x1] * lx1);
+    return __builtin_fmaf(a, ly0, b * ly1);
+}
+
+__global__ void __launch_bounds__(64)
+collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict__ inds,
+                     const float *__restrict__ offs, int off_lowres, int C, int H, int W,
+                     const int32_t *__restrict__ jf, const int32_t *__restrict__ jt, int L, int K,
+                     float thre, float min_len, float resize, float *__restrict__ limbs)
+{
+    extern __shared__ float sm[];
+    float *tx = sm, *ty = sm + K, *ts = sm + 2 * K;
+    int *ti = reinterpret_cast<int *>(sm + 3 * K);
+    const int n = blockIdx.x / L, l = blockIdx.x % L, lane = threadIdx.x;
+    const int cf = jf[l], ct = jt[l];
+    const long HW = (long)H * W;
+    const float *sf = scores + ((size_t)n * C + cf) * K, *st = scores + ((size_t)n * C + ct) * K;
+    const int64_t *idf = inds + ((size_t)n * C + cf) * K, *idt = inds + ((size_t)n * C + ct) * K;
+
+    for (int m = lane; m < K; m += 64) {
+        const int64_t id = idt[m];
+        int64_t x = id % W, y = id / W;
+        const float s = st[m];
+        if (s < thre) { x -= 100000; y -= 100000; }  // collect.py:253
+        tx[m] = (float)x;
+        ty[m] = (float)y;
+        ts[m] = s;
+        ti[m] = (int)id;
+    }
+    __syncthreads();
+
+    for (int k = lane; k < K; k += 64) {
+        const int64_t id = idf[k];
+        const int xi = (int)(id % W), yi = (int)(id / W);
+        const float s1 = sf[k];
+        int64_t xs = xi, ys = yi;
+        if (s1 < thre) { xs -= 100000; ys -= 100000; }
+        const float xf = (float)xs, yf = (float)ys;
+        float ox, oy;  // offset at the ORIGINAL flat index (collect.py:143-147)
+        if (off_lowres) {
+            const int h4 = H / 4, w4 = W / 4;
+            const float *px = offs + ((size_t)n * 2 * L + 2 * l) * h4 * w4;
+            ox = bilinear4_at(px, h4, w4, yi, xi);
+            oy = bilinear4_at(px + (size_t)h4 * w4, h4, w4, yi, xi);
+        } else {
+            const float *px = offs + ((size_t)n * 2 * L + 2 * l) * HW;
+            ox = px[id];
+            oy = px[HW + id];
+        }
+        const float gx = xf + ox * resize, gy = yf + oy * resize;  // collect.py:152
+        int best = 0;
+        float bd = INFINITY;
+        for (int m = 0; m < K; ++m) {  // collect.py:171-177
+            const float dx = gx - tx[m], dy = gy - ty[m];
+            const float d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+            if (d < bd) { bd = d; best = m; }
+        }
+        const float x2 = tx[best], y2 = ty[best], s2 = ts[best];
+        const float lx = xf - x2, ly = yf - y2;
+        float len = sqrtf(__builtin_fmaf(ly, ly, lx * lx));
+        len = len < min_len ? min_len : len;                        // collect.py:204-205
+        const float sc = (s1 * s2) * expf(-bd / len);                // collect.py:208
+        float *o = limbs + (((size_t)n * L + l) * K + k) * 13;
+        o[0] = xf; o[1] = yf; o[2] = s1;
+        o[3] = x2; o[4] = y2; o[5] = s2;
+        o[6] = (float)(id + (int64_t)cf * HW);                       // collect.py:194-199, :227-228
+        o[7] = (float)((int64_t)ti[best] + (int64_t)ct * HW);
+        o[8] = bd; o[9] = len; o[10] = sc; o[11] = 4.f; o[12] = 4.f;
+    }
+}
+
+}  // namespace
+
+OG_API int og_collect_limbs_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                                int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                                float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream)
+{
+    const char *name = "og_collect_limbs_f32";
+    OG_REQUIRE(scores && inds && offs && jf && jt && limbs, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && L > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(!off_is_lowres || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
+    OG_REQUIRE((long)H * W < (1l << 31), OG_EINVAL, "%s: plane too large", name);
+    OG_REQUIRE(k <= 2048, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
+    hipLaunchKernelGGL(collect_limbs_kernel, dim3(N * L), dim3(64), (size_t)k * 16, (hipStream_t)stream, scores, inds,
+                       offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

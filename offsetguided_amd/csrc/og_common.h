@@ -1,0 +1,66 @@
+// Shared helpers of libog_decoder.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "og_decoder.h"
+
+#define OG_API extern "C" __attribute__((visibility("default")))
+
+void og_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define OG_REQUIRE(cond, code, ...)  \
+    do {                             \
+        if (!(cond)) {               \
+            og_set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+
+// Launch-error check only: never synchronises.
+#define OG_LAUNCH_CHECK(name)                                                      \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            og_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_)); \
+            return OG_EHIP;                                                        \
+        }                                                                          \
+    } while (0)
+
+static inline size_t og_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// XCD-aware work mapping: hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs, so ids b and b+8 share an L2.  Remap so that CONSECUTIVE work items (bands of one
+// plane, which share halo rows) land on one XCD.  `padded` = grid size (multiple of 8).
+__device__ __forceinline__ int og_xcd_remap(int bid, int padded)
+{
+    return (bid & 7) * (padded >> 3) + (bid >> 3);
+}
+
+// Whole-wave shifts by one lane (gfx9 DPP wave_shr / wave_shl); lanes without a source get 0.
+__device__ __forceinline__ float og_from_lane_below(float v)  // lane i <- lane i-1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float og_from_lane_above(float v)  // lane i <- lane i+1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float og_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Order-preserving 64-bit key: larger key = earlier in (value desc, index asc) order.
+__device__ __forceinline__ uint64_t og_make_key(float v, uint32_t idx)
+{
+    v = (v == 0.f) ? 0.f : v;  // -0.0 ranks with +0.0
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)~idx;
+}
+__device__ __forceinline__ float og_key_value(uint64_t k)
+{
+    uint32_t u = (uint32_t)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ uint32_t og_key_index(uint64_t k) { return ~(uint32_t)k; }

@@ -1,0 +1,82 @@
+"""Candidate limb collection (reference decoder/collect.py:21-273) on the HIP kernels K1+K2."""
+import logging
+
+import torch
+
+from .. import _lib
+from ..config.coco_data import COCO_KEYPOINTS, COCO_PERSON_SKELETON
+from .heatmap import joint_dets
+
+LOG = logging.getLogger(__name__)
+
+
+class LimbsCollect(object):
+    """Pairs top-k keypoint candidates into limbs along the guiding offsets.
+
+    Same constructor and `generate_limbs` contract as the reference class
+    (decoder/collect.py:37-67).  The output rows are
+    [x1, y1, v1, x2, y2, v2, ind1, ind2, len_delta, len_limb, limb_score, scale1, scale2].
+    Keypoint-scale and jitter-offset heads (off in every published configuration) are not
+    implemented on the device path and raise.
+    """
+
+    def __init__(self, hmp_s, off_s, *, topk=40, thre_hmp=0.08, min_len=3,
+                 include_jitter_offset=False, include_scale=False, use_jitter_offset=True,
+                 keypoints=COCO_KEYPOINTS, skeleton=COCO_PERSON_SKELETON):
+        self.hmp_s = hmp_s
+        self.off_s = off_s
+        self.resize_factor = off_s / hmp_s
+        self.keypoints = keypoints
+        self.skeleton = skeleton
+        self.K = topk
+        self.thre_hmp = thre_hmp
+        self.min_len = min_len
+        self.include_jitter_offset = include_jitter_offset
+        self.include_scale = include_scale
+        self.use_jitter_offset = use_jitter_offset
+        self.jtypes_f, self.jtypes_t = self.pack_jtypes(skeleton)
+        LOG.info('%d limbs, keypoint threshold %.4f, offset/heatmap unit ratio %.3f',
+                 len(skeleton), thre_hmp, self.resize_factor)
+
+    @staticmethod
+    def pack_jtypes(skeleton):
+        return [a for a, _ in skeleton], [b for _, b in skeleton]
+
+    def _check_optional_heads(self, jomps_hr, scmps_hr, vector_nd):
+        if self.include_scale and isinstance(scmps_hr, torch.Tensor):
+            raise NotImplementedError('keypoint-scale head is not supported by the HIP decoder')
+        if self.include_jitter_offset and isinstance(jomps_hr, torch.Tensor):
+            raise NotImplementedError('jitter-offset head is not supported by the HIP decoder')
+        if vector_nd != 2:
+            raise NotImplementedError('only 2-D guiding offsets (vector_nd=2) are supported; '
+                                      'cat_flip_offs builds 4-D ones')
+
+    def generate_limbs(self, hmps_hr, jomps_hr, offs_hr, scmps_hr, vector_nd=2):
+        """(N,C,H,W) heatmaps + (N,2L,H,W) offsets at input resolution -> limbs (N,L,K,13)."""
+        assert hmps_hr.shape[-2:] == offs_hr.shape[-2:], 'spatial resolution should be equal'
+        self._check_optional_heads(jomps_hr, scmps_hr, vector_nd)
+        return self._collect(hmps_hr, offs_hr, off_is_lowres=False)
+
+    def generate_limbs_lowres(self, hmps_hr, offs_lr):
+        """Same result as generate_limbs(hmps_hr, [], F.interpolate(offs_lr, x4, 'bilinear'), [])
+        without building the hi-res offset tensor: K2 samples it at the candidate peaks."""
+        assert hmps_hr.shape[-2] == 4 * offs_lr.shape[-2] and hmps_hr.shape[-1] == 4 * offs_lr.shape[-1], \
+            'spatial resolution should be equal'
+        return self._collect(hmps_hr, offs_lr, off_is_lowres=True)
+
+    def _collect(self, hmps_hr, offs, off_is_lowres):
+        hmps_hr = _lib.require_device(hmps_hr, 'hmps_hr')
+        offs = _lib.require_device(offs, 'offs')
+        n, c, h, w = hmps_hr.shape
+        n_limbs = len(self.skeleton)
+        assert offs.shape[1] == 2 * n_limbs, 'offset channels must be 2 x number of limbs'
+        scores, inds, _, _ = joint_dets(hmps_hr, self.K)
+        dev = hmps_hr.device
+        lib = _lib.load()
+        limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
+        _lib.check(lib.og_collect_limbs_f32(
+            _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,
+            _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
+            n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
+            _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)
+        return limbs

@@ -1,0 +1,175 @@
+"""PostProcess / decoder_cli / decoder_factory -- the decoder's drop-in boundary
+(reference decoder/factory.py:21-267).
+
+generate_poses keeps the reference signature and return type (list of float32 (M,17,6) arrays)
+but runs the whole post-processing on the GPU:
+    K0 flip merge -> K1a bicubic x4 -> K1 NMS+top-k -> K2 limb collection (offsets sampled from
+    the stride-4 map, the hi-res offset tensor is never built) -> K3 greedy grouping,
+with a single device->host copy of the finished poses.  No multiprocessing.Pool is created.
+"""
+import logging
+import re
+
+import torch
+
+from .. import _lib
+from .. import config
+from ..config.coco_data import (COCO_KEYPOINTS, COCO_PERSON_SKELETON, COCO_PERSON_WITH_REDUNDANT_SKELETON,
+                                DENSER_COCO_PERSON_SKELETON, KINEMATIC_TREE_SKELETON, REDUNDANT_CONNECTIONS)
+from ..utils import boolean_string
+from .collect import LimbsCollect
+from .group import GreedyGroup
+from .offset import pack_jtypes, scored_offset
+
+LOG = logging.getLogger(__name__)
+
+
+def upsample4(x, mode):
+    """F.interpolate(x, scale_factor=4, mode=mode) with torch-CPU fp32 rounding, as a HIP kernel."""
+    x = _lib.require_device(x, 'feature map')
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
+    fn = {'bicubic': lib.og_upsample_bicubic4_f32, 'bilinear': lib.og_upsample_bilinear4_f32}[mode]
+    _lib.check(fn(_lib.ptr(x), n * c, h, w, _lib.ptr(out), _lib.stream_ptr(x.device)), lib)
+    return out
+
+
+class PostProcess(torch.nn.Module):
+    def __init__(self, batch_size, hmp_stride, off_stride, inter_mode, keypoints, skeleton,
+                 limb_collector, limb_grouper, include_scale=False, include_jitter_offset=False,
+                 hmp_index=0, omp_index=1, feat_stage=-1):
+        super().__init__()
+        if hmp_stride != 4 or off_stride != 4:
+            raise NotImplementedError('the HIP decoder is built for the stride-4 heads of Hourglass-104')
+        if inter_mode not in ('bicubic', 'bilinear'):
+            raise ValueError(f'unknown resize mode {inter_mode}')
+        self.batch_size = batch_size
+        self.inter_mode = inter_mode
+        self.hmp_stride = hmp_stride
+        self.off_stride = off_stride
+        self.keypoints = keypoints
+        self.skeleton = skeleton
+        self.limb_collect = limb_collector
+        self.limb_group = limb_grouper
+        self.hmp_index = hmp_index
+        self.omp_index = omp_index
+        self.feat_stage = feat_stage
+        self.include_scale = include_scale
+        self.include_jitter_offset = include_jitter_offset
+        self.keypoints_flips = config.heatmap_hflip(keypoints)
+        self.limbs_flips = config.offset_hflip(keypoints, skeleton)
+        self.worker_pool = None  # grouping runs on the device; kept as an attribute for API parity
+        LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
+                 'device-resident grouping', feat_stage, hmp_index, omp_index, inter_mode)
+
+    # ---- reference API -------------------------------------------------------------------
+    def generate_poses(self, features, flip_test=False, cat_flip_offs=False, scored_off=False):
+        limbs = self.generate_limbs(features, flip_test, cat_flip_offs, scored_off)
+        return self.limb_group.group_batch(limbs)
+
+    def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
+        """Merge the predictions for [images, mirrored images] (decoder/factory.py:98-146)."""
+        if cat_flip_offs:
+            raise NotImplementedError('cat_flip_offs (4-D offsets, -0.5 AP in the reference) is not supported')
+        if (self.include_jitter_offset and isinstance(jomps, torch.Tensor)) or \
+                (self.include_scale and isinstance(scmps, torch.Tensor)):
+            raise NotImplementedError('jitter/scale heads are not supported by the HIP decoder')
+        hmps = _lib.require_device(hmps, 'hmps')
+        offs = _lib.require_device(offs, 'offs')
+        n2, c, h, w = hmps.shape
+        n, n_limbs = n2 // 2, offs.shape[1] // 2
+        dev = hmps.device
+        lib = _lib.load()
+        keep = [1 if l in self.limbs_flips[1] else 0 for l in range(n_limbs)]
+        hm_out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        off_out = torch.empty((n, 2 * n_limbs, h, w), dtype=torch.float32, device=dev)
+        _lib.check(lib.og_flip_merge_f32(
+            _lib.ptr(hmps), _lib.ptr(offs), n, c, n_limbs, h, w,
+            _lib.ptr(_lib.int_table(self.keypoints_flips, dev)), _lib.ptr(_lib.int_table(self.limbs_flips[0], dev)),
+            _lib.ptr(_lib.int_table(keep, dev)), _lib.ptr(hm_out), _lib.ptr(off_out), _lib.stream_ptr(dev)), lib)
+        return hm_out, jomps, off_out, scmps, vector_nd
+
+    # ---- device-resident pieces ----------------------------------------------------------
+    def generate_limbs(self, features, flip_test=False, cat_flip_offs=False, scored_off=False):
+        """Everything up to (not including) grouping; returns the (N, L, K, 13) limbs tensor."""
+        out_hmps, _, out_jomps = features[self.hmp_index]
+        out_offsets, _, out_scales = features[self.omp_index]
+        hmps = out_hmps[self.feat_stage]
+        jomps = out_jomps[self.feat_stage]
+        offs = out_offsets[self.feat_stage]
+        scmps = out_scales[self.feat_stage]
+        if (self.include_scale and isinstance(scmps, torch.Tensor)) or \
+                (self.include_jitter_offset and isinstance(jomps, torch.Tensor)):
+            raise NotImplementedError('jitter/scale heads are not supported by the HIP decoder')
+        if flip_test:
+            hmps, jomps, offs, scmps, _ = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, 2)
+        if scored_off:
+            jf, jt = pack_jtypes(self.skeleton)
+            offs = scored_offset(hmps.float(), offs.float(), jf, jt, kernel_size=3)
+        hmps_hr = upsample4(hmps, self.inter_mode)
+        return self.limb_collect.generate_limbs_lowres(hmps_hr, offs)
+
+
+def decoder_cli(parser):
+    """Command-line flags of the decoder (same names and defaults as decoder/factory.py:149-188)."""
+    g = parser.add_argument_group('limb collections in post-processing')
+    g.add_argument('--resize-mode', default='bicubic', choices=['bilinear', 'bicubic'], type=str,
+                   help='interpolation used to bring the keypoint heatmaps to input resolution')
+    g.add_argument('--topk', default=48, type=int,
+                   help='responses kept per heatmap channel (= candidate limbs per limb type)')
+    g.add_argument('--thre-hmp', default=0.06, type=float,
+                   help='candidate keypoints below this response are pushed outside the image')
+    g.add_argument('--min-len', default=0.5, type=float,
+                   help='lower clamp (pixels) on candidate limb length')
+    g.add_argument('--feat-stage', default=-1, type=int, help='hourglass stack whose outputs are decoded')
+    g = parser.add_argument_group('greedy grouping in post-processing')
+    g.add_argument('--person-thre', default=0.06, type=float, help='minimum mean keypoint score of a pose')
+    g.add_argument('--sort-dim', default=2, choices=[2, 4], type=int,
+                   help='pose field used for scoring/sorting: 2 keypoint score, 4 limb score')
+    g.add_argument('--dist-max', default=20, type=float,
+                   help='reject limbs whose guided endpoint misses the matched keypoint by more than this')
+    g.add_argument('--use-scale', default=True, type=boolean_string,
+                   help='with a keypoint-scale head: scale-dependent limb rejection')
+    g.add_argument('--use-jitter-offset', default=True, type=boolean_string,
+                   help='with a jitter-offset head: refine keypoint positions')
+
+
+_SKELETONS = {'omp': COCO_PERSON_SKELETON, 'omps': COCO_PERSON_SKELETON, 'omp19': COCO_PERSON_SKELETON,
+              'offset': COCO_PERSON_SKELETON, 'offsets': COCO_PERSON_SKELETON,
+              'omp16': KINEMATIC_TREE_SKELETON, 'omp31': COCO_PERSON_WITH_REDUNDANT_SKELETON,
+              'omp44': DENSER_COCO_PERSON_SKELETON, 'omp25': REDUNDANT_CONNECTIONS, 'omps25': REDUNDANT_CONNECTIONS}
+
+
+def parse_heads(head_name, stride):
+    """Head name -> decoder configuration (decoder/factory.py:191-231).
+
+    Two reference slips are fixed on purpose: 'omps' / 'offset' are accepted individually (a
+    missing comma fuses them there, :212-213) and 'hmp17' works (UnboundLocalError there, :201-209)."""
+    m = re.match('hmp[s]?([0-9]+)$', head_name)
+    if head_name in ('hmp', 'hmps', 'heatmap', 'heatmaps') or m is not None:
+        if m is not None:
+            assert int(m.group(1)) == 17, f'{m.group(1)} keypoints not supported'
+        return {'keypoints': COCO_KEYPOINTS, 'hmp_stride': stride}
+    if head_name in ('omp', 'omps', 'offset', 'offsets') or re.match('omp[s]?([0-9]+)$', head_name) is not None:
+        if head_name not in _SKELETONS:
+            raise Exception('unknown skeleton type of head')
+        return {'skeleton': _SKELETONS[head_name], 'omp_stride': stride}
+    raise Exception('unknown head to create an encoder: {}'.format(head_name))
+
+
+def decoder_factory(args):
+    """Build a PostProcess from parsed flags (decoder/factory.py:234-267)."""
+    cfg = {}
+    for name, stride in zip(args.headnets, args.strides):
+        cfg.update(parse_heads(name, stride))
+    collector = LimbsCollect(cfg['hmp_stride'], cfg['omp_stride'], topk=args.topk, thre_hmp=args.thre_hmp,
+                             min_len=args.min_len, include_jitter_offset=args.include_jitter_offset,
+                             include_scale=args.include_scale, use_jitter_offset=args.use_jitter_offset,
+                             keypoints=cfg['keypoints'], skeleton=cfg['skeleton'])
+    grouper = GreedyGroup(args.person_thre, sort_dim=args.sort_dim, dist_max=args.dist_max,
+                          use_scale=args.use_scale, keypoints=cfg['keypoints'], skeleton=cfg['skeleton'])
+    return PostProcess(args.batch_size, cfg['hmp_stride'], cfg['omp_stride'], args.resize_mode,
+                       keypoints=cfg['keypoints'], skeleton=cfg['skeleton'], limb_collector=collector,
+                       limb_grouper=grouper, include_scale=args.include_scale,
+                       include_jitter_offset=args.include_jitter_offset, feat_stage=args.feat_stage)

@@ -1,0 +1,54 @@
+"""Keypoint candidate detection: 3x3 max-NMS and per-channel top-k on hi-res heatmaps.
+
+API of the reference's decoder/heatmap.py (hmp_NMS :15-35, topK_channel :38-49, joint_dets
+:52-59); layout is NCHW (the reference docstring says NHWC but its code pools the last two
+dims).  `topk_ys` uses floor division -- the reference pins torch 1.3.1, where int64 / int
+floors, and its own demo indexes arrays with the result (demo_batch.py:236-237).
+"""
+import torch
+
+from .. import _lib
+
+
+def _planes(t):
+    n, c, h, w = t.shape
+    return n * c, h, w
+
+
+def hmp_NMS(heat, kernel=3):
+    """Keep 3x3 local maxima (zero padding), zero the rest: heat * (maxpool(heat) == heat)."""
+    if kernel != 3:
+        raise NotImplementedError("hmp_NMS: only the 3x3 window used by the decoder is implemented")
+    heat = _lib.require_device(heat, "hmp_NMS(heat)")
+    lib = _lib.load()
+    planes, h, w = _planes(heat)
+    out = torch.empty_like(heat)
+    _lib.check(lib.og_hmp_nms_f32(_lib.ptr(heat), planes, h, w, _lib.ptr(out), _lib.stream_ptr(heat.device)), lib)
+    return out
+
+
+def _topk(entry, scores, K):
+    scores = _lib.require_device(scores, "scores")
+    lib = _lib.load()
+    n, c, h, w = scores.shape
+    if K > h * w:
+        raise RuntimeError("selected index k out of range")  # torch.topk's message
+    dev = scores.device
+    out_s = torch.empty((n, c, K), dtype=torch.float32, device=dev)
+    out_i = torch.empty((n, c, K), dtype=torch.int64, device=dev)
+    nbytes = lib.og_topk_workspace_bytes(n * c, h, w, K)
+    ws = _lib.workspace(dev, nbytes, "topk")
+    fn = getattr(lib, entry)
+    _lib.check(fn(_lib.ptr(scores), n * c, h, w, K, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(ws), ws.numel(),
+                  _lib.stream_ptr(dev)), lib)
+    return out_s, out_i, torch.div(out_i, w, rounding_mode='floor'), out_i % w
+
+
+def topK_channel(scores, K=40):
+    """Top-K responses of every (n, c) plane: (scores, flat idx, ys, xs), each (N, C, K)."""
+    return _topk("og_topk_channel_f32", scores, K)
+
+
+def joint_dets(hmps, k):
+    """topK_channel(hmp_NMS(hmps), k) in ONE pass over the heatmaps (the NMS map is never stored)."""
+    return _topk("og_nms_topk_f32", hmps, k)

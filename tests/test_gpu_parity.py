@@ -1,0 +1,269 @@
+"""GPU parity: the HIP kernels (through the C ABI / the drop-in Python API) against the CPU oracle
+and the committed golden vectors.  Bit-exact for indices, coordinates, grouping; <= 1e-4 for scores
+(tolerance stated by the north star; observed ~1e-7, the device exp() differs from Sleef by <= 1 ulp)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from offsetguided_amd import _lib, decoder, synth
+from offsetguided_amd.config import coco_data as cd
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, load_case,
+                     split_poses)
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def processor(batch=2, **over):
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    f = dict(FLAGS, **over)
+    a = p.parse_args(['--topk', str(f['topk']), '--thre-hmp', str(f['thre_hmp']), '--person-thre',
+                      str(f['person_thre']), '--dist-max', str(f['dist_max']), '--min-len', str(f['min_len'])])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], batch
+    a.include_scale = a.include_jitter_offset = False
+    return decoder.decoder_factory(a)
+
+
+def features(hm, off, dev):
+    hm, off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+    return [([hm * 0, hm], [[], []], [[], []]), ([off * 0, off], [[], []], [[], []])]
+
+
+# ------------------------------------------------------------------ upsampling (a5)
+@pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 2, 7, 61), (1, 1, 1, 1), (1, 2, 5, 130), (2, 17, 160, 160)])
+def test_bicubic_bit_exact(dev, shape):
+    x = synth.noise_batch(21, shape)
+    got = decoder.factory.upsample4(torch.from_numpy(x).to(dev), 'bicubic').cpu().numpy()
+    assert (got == oracle.bicubic4(x)).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 2, 7, 61), (1, 1, 1, 1), (1, 38, 64, 64)])
+def test_bilinear_bit_exact(dev, shape):
+    x = synth.noise_batch(22, shape)
+    got = decoder.factory.upsample4(torch.from_numpy(x).to(dev), 'bilinear').cpu().numpy()
+    assert (got == oracle.bilinear4(x)).all()
+
+
+# ------------------------------------------------------------------ NMS / top-k (a6-a8)
+NMS_SHAPES = [(2, 3, 37, 53), (1, 2, 64, 64), (1, 1, 3, 250), (1, 2, 33, 252), (1, 1, 70, 640), (1, 1, 9, 1000)]
+
+
+@pytest.mark.parametrize("shape", NMS_SHAPES)
+def test_hmp_nms_exact(dev, shape):
+    z = synth.noise_batch(23, shape)
+    got = decoder.hmp_NMS(torch.from_numpy(z).to(dev)).cpu().numpy()
+    ref = oracle.hmp_nms(z)
+    assert (got == ref).all() and (np.signbit(got) == np.signbit(ref)).all()
+
+
+@pytest.mark.parametrize("shape", NMS_SHAPES)
+@pytest.mark.parametrize("k", [1, 9, 32, 100])
+def test_topk_channel_exact(dev, shape, k):
+    z = synth.noise_batch(24, shape)
+    if k > shape[2] * shape[3]:
+        pytest.skip("k > plane")
+    for inp in (z, oracle.hmp_nms(z)):  # plain noise, and an NMS map (mostly +-0 -> index tie rule)
+        s, i, ys, xs = decoder.topK_channel(torch.from_numpy(inp).to(dev), K=k)
+        rs, ri, ry, rx = oracle.topk(inp, k)
+        assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+        assert (ys.cpu().numpy() == ry).all() and (xs.cpu().numpy() == rx).all()
+
+
+@pytest.mark.parametrize("shape", NMS_SHAPES)
+@pytest.mark.parametrize("k", [1, 32, 48, 200])
+def test_joint_dets_exact(dev, shape, k):
+    z = synth.noise_batch(25, shape)
+    if k > 2 * (shape[2] + shape[3]) - 4:
+        pytest.skip("plane border smaller than k")
+    s, i, ys, xs = decoder.joint_dets(torch.from_numpy(z).to(dev), k)
+    rs, ri, ry, rx = oracle.nms_topk(z, k)
+    assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+    assert (ys.cpu().numpy() == ry).all() and (xs.cpu().numpy() == rx).all()
+
+
+def test_joint_dets_degenerate_planes(dev):
+    """All-zero, constant, negative-only and plateau planes: filler order = lowest zero-valued index."""
+    H, W, k = 40, 48, 32
+    planes = np.zeros((1, 6, H, W), np.float32)
+    planes[0, 1] = 0.5                                   # constant positive: every pixel is a peak (ties by index)
+    planes[0, 2] = -1.0                                  # constant negative: interior kept (negative), border -> -0
+    planes[0, 3, 10:14, 20:30] = 0.7                     # plateau
+    planes[0, 4] = -np.abs(synth.noise_batch(3, (H, W)))  # negative noise with negative interior peaks
+    planes[0, 5, 0, :5] = [0.3, 0.0, 0.2, 0.0, 0.1]      # peaks on the first row, zeros between
+    s, i, _, _ = decoder.joint_dets(torch.from_numpy(planes).to(dev), k)
+    rs, ri, _, _ = oracle.nms_topk(planes, k)
+    assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+
+
+def test_topk_errors(dev):
+    z = torch.zeros(1, 1, 4, 5, device=dev)
+    with pytest.raises(RuntimeError):
+        decoder.topK_channel(z, K=21)
+    with pytest.raises(_lib.OgError):
+        decoder.joint_dets(torch.zeros(1, 1, 4, 5), 2)   # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ limbs (a9-a10)
+@pytest.mark.parametrize("name", ["pipe256_p6", "pipe256_p20", "pipe640"])
+def test_collect_limbs_both_offset_forms(dev, name):
+    g, hm, off = load_case(name)
+    proc = processor(int(g["batch"]))
+    hr = oracle.bicubic4(hm)
+    ohr = oracle.bilinear4(off)
+    t_hr = torch.from_numpy(hr).to(dev)
+    l_hi = proc.limb_collect.generate_limbs(t_hr, [], torch.from_numpy(ohr).to(dev), []).cpu().numpy()
+    l_lo = proc.limb_collect.generate_limbs_lowres(t_hr, torch.from_numpy(off).to(dev)).cpu().numpy()
+    assert (l_hi == l_lo).all()
+    assert_limbs_match(g["limbs"], l_hi, SCORE_TOL)
+
+
+def test_collect_spatial_mismatch_asserts(dev):
+    proc = processor()
+    with pytest.raises(AssertionError):
+        proc.limb_collect.generate_limbs(torch.zeros(1, 17, 64, 64, device=dev), [],
+                                         torch.zeros(1, 38, 32, 32, device=dev), [])
+
+
+# ------------------------------------------------------------------ grouping (a12)
+def test_grouping_golden_adversarial(dev):
+    g = np.load(f"{GOLDEN}/grouping_adversarial.npz")
+    for si, sk_name in enumerate(g["skeleton_names"]):
+        sk = getattr(cd, str(sk_name))
+        o = 0
+        for limbs, (K, M), cfg in zip(g[f"limbs_{si}"], g[f"kn_{si}"], g[f"cfg_{si}"]):
+            thre, dmax, use_scale, sort_dim = g["cfg_table"][cfg]
+            G = decoder.GreedyGroup(thre, sort_dim=int(sort_dim), dist_max=dmax, use_scale=bool(use_scale), skeleton=sk)
+            got = G.group_skeletons(np.ascontiguousarray(limbs[:, :K]))
+            ref = g[f"poses_{si}"][o:o + M]
+            o += M
+            assert got.shape == ref.shape and (got == ref).all(), f"{sk_name} case"
+
+
+@pytest.mark.parametrize("sk_name", ["COCO_PERSON_SKELETON", "DENSER_COCO_PERSON_SKELETON"])
+def test_grouping_fuzz_vs_oracle(dev, sk_name):
+    import sys
+    sys.path.insert(0, "tools")
+    sk = getattr(cd, sk_name)
+    L = len(sk)
+    rng0 = synth.HashRng(4242)
+    cases = []
+    for i in range(96):
+        rng = synth.HashRng(880000 + i)
+        K = int(rng.integers(1, 2, 12)[0])
+        cases.append(_adversarial(rng, K, sk))
+    G = decoder.GreedyGroup(0.04, sort_dim=2, dist_max=40.0, use_scale=False, skeleton=sk)
+    for K in sorted({c.shape[1] for c in cases}):
+        batch = np.stack([c for c in cases if c.shape[1] == K])
+        got = G.group_batch(torch.from_numpy(batch).to(dev))
+        for lim, p in zip(batch, got):
+            ref = oracle.greedy_group(lim, sk, 17, 0.04, 40.0)
+            assert p.shape == ref.shape and (p == ref).all()
+    assert L == len(sk) and rng0 is not None
+
+
+def _adversarial(rng, K, skeleton, hw=4096):
+    """Same collision-heavy generator as tools/gen_golden.py (mode 1), self-contained for the GPU box."""
+    L = len(skeleton)
+    pool = int(rng.integers(1, 1, 3)[0])
+    cand_xy = rng.uniform(17 * pool * 2, 1.0, 200.0).reshape(17, pool, 2).round()
+    cand_v = rng.uniform(17 * pool, 0.05, 1.0).reshape(17, pool)
+    P = int(rng.integers(1, 2, 5)[0])
+    pid = rng.integers(P * 17, 0, pool - 1).reshape(P, 17)
+    limbs = np.zeros((L, K, 13), np.float32)
+    for l, (a, b) in enumerate(skeleton):
+        order = np.argsort(rng.uniform(P))
+        take, cross, other = rng.uniform(P) < 0.8, rng.uniform(P) < 0.3, rng.integers(P, 0, P - 1)
+        fl, tl = [], []
+        for p in order:
+            if take[p] and pid[p, a] not in fl:
+                fl.append(pid[p, a])
+                tl.append(pid[other[p], b] if cross[p] else pid[p, b])
+        fl, tl = fl[:K], tl[:K]
+        sc = rng.uniform(K, 0.01, 1.0) * 10.0 ** -float(rng.integers(1, 0, 2)[0])
+        dist = rng.uniform(K, 0.0, 45.0)
+        for k in range(K):
+            if k < len(fl):
+                f, t = fl[k], tl[k]
+                limbs[l, k] = [cand_xy[a, f, 0], cand_xy[a, f, 1], cand_v[a, f], cand_xy[b, t, 0], cand_xy[b, t, 1],
+                               cand_v[b, t], a * hw + f, b * hw + t, dist[k], 10.0, sc[k], 4.0, 4.0]
+            else:
+                limbs[l, k] = [-99990.0, -99980.0, 0.001, -99970.0, -99960.0, 0.002, a * hw + pool + k,
+                               b * hw + pool + k, 5.0, 10.0, 1e-6 * (k + 1), 4.0, 4.0]
+    return limbs
+
+
+def test_grouping_table_overflow_retry(dev):
+    """More live partial skeletons than the LDS table holds -> flagged, retried with a larger table."""
+    sk = cd.COCO_PERSON_SKELETON
+    K = 40
+    limbs = np.zeros((len(sk), K, 13), np.float32)
+    for l, (a, b) in enumerate(sk):          # every limb row is an isolated 2-keypoint skeleton
+        for k in range(K):
+            uid = l * K + k
+            limbs[l, k] = [1 + uid, 2 + uid, 0.5, 3 + uid, 4 + uid, 0.6, a * 500000 + uid, b * 500000 + uid,
+                           1.0, 10.0, 0.3 + 1e-4 * uid, 4.0, 4.0]
+    G = decoder.GreedyGroup(0.04, dist_max=40.0, skeleton=sk)
+    got = G.group_skeletons(limbs)
+    ref = oracle.greedy_group(limbs, sk, 17, 0.04, 40.0)
+    assert len(ref) > G.MMAX
+    assert got.shape == ref.shape and (got == ref).all()
+
+
+# ------------------------------------------------------------------ flip merge (a4) + whole pipeline
+@pytest.mark.parametrize("name", ["pipe256_flip_p6", "pipe640_flip"])
+def test_flip_merge_exact(dev, name):
+    g, hm, off = load_case(name)
+    proc = processor(int(g["batch"]))
+    mh, _, mo, _, _ = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], False, 2)
+    rh, ro = oracle.flip_merge(hm, off, *flip_tables())
+    assert (mh.cpu().numpy() == rh).all() and (mo.cpu().numpy() == ro).all()
+
+
+@pytest.mark.parametrize("name", PIPE_CASES)
+def test_generate_poses_golden(dev, name):
+    """Drop-in surface: decoder_factory(args).generate_poses(features, flip_test) vs the reference's output."""
+    g, hm, off = load_case(name)
+    proc = processor(int(g["batch"]))
+    feats = features(hm, off, dev)
+    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"])).cpu().numpy()
+    assert_limbs_match(g["limbs"], limbs, SCORE_TOL)
+    poses = proc.generate_poses(feats, flip_test=bool(g["flip"]))
+    assert all(p.dtype == np.float32 for p in poses)
+    assert_poses_match(split_poses(g), poses, SCORE_TOL)
+
+
+def test_full_size_batch_properties(dev):
+    """bs8 640x640 (BASELINE config 2): size-independent properties + oracle on the same maps."""
+    hm, off = synth.synth_batch(7, 8, 640, 640)
+    proc = processor(8)
+    t_hr = decoder.factory.upsample4(torch.from_numpy(hm).to(dev), 'bicubic')
+    s, i, ys, xs = decoder.joint_dets(t_hr, 32)
+    s_h, i_h = s.cpu().numpy(), i.cpu().numpy()
+    assert (np.diff(s_h, axis=-1) <= 0).all()                                  # sorted descending
+    assert all(len(set(r)) == 32 for r in i_h.reshape(-1, 32))                 # distinct pixels
+    flat = t_hr.view(8, 17, -1)
+    assert (torch.gather(flat, 2, i) == s).all()                              # scores are the map values there
+    nms = decoder.hmp_NMS(t_hr)
+    assert (torch.gather(nms.view(8, 17, -1), 2, i) == s).all()               # and they are NMS survivors
+    s2, i2, _, _ = decoder.topK_channel(nms, K=32)                             # fused == unfused
+    assert (s2 == s).all() and (i2 == i).all()
+    assert (decoder.hmp_NMS(nms) == nms).all()                                 # NMS is idempotent
+    rs, ri, _, _ = oracle.nms_topk(oracle.bicubic4(hm[:2]), 32)                # oracle on two images
+    assert (s_h[:2] == rs).all() and (i_h[:2] == ri).all()
+    poses = proc.generate_poses(features(hm, off, dev))
+    ref_poses, _ = oracle.decode(hm[:2], off[:2], cd.COCO_PERSON_SKELETON, topk_k=32, thre_hmp=FLAGS["thre_hmp"],
+                                 min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"])
+    assert_poses_match(ref_poses, poses[:2], SCORE_TOL)
+    assert len(poses) == 8
