@@ -259,7 +259,8 @@ def test_full_size_batch_properties(dev):
     assert (torch.gather(nms.view(8, 17, -1), 2, i) == s).all()               # and they are NMS survivors
     s2, i2, _, _ = decoder.topK_channel(nms, K=32)                             # fused == unfused
     assert (s2 == s).all() and (i2 == i).all()
-    assert (decoder.hmp_NMS(nms) == nms).all()                                 # NMS is idempotent
+    nms2 = decoder.hmp_NMS(nms)                                                # idempotent on the positive peaks
+    assert ((nms2 == nms) | (nms < 0)).all() and ((nms2 > 0) == (nms > 0)).all()
     rs, ri, _, _ = oracle.nms_topk(oracle.bicubic4(hm[:2]), 32)                # oracle on two images
     assert (s_h[:2] == rs).all() and (i_h[:2] == ri).all()
     poses = proc.generate_poses(features(hm, off, dev))
