@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s end-to-end (Hourglass-104 backbone + heads + HIP decoder) at
+640x640, batch 8 per GPU, synthetic data, plus decoder-only ms/img.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run,
+                                                        one rank per GPU, no data-path collective)
+
+A step = one batch of 8 images (16 through the backbone with --flip) resident in HBM:
+bf16 channels-last backbone replayed as a HIP graph -> head outputs (+ synthetic GT-like
+maps, see below) -> K1a bicubic x4 -> K1 NMS+top-k -> K2 limb collection -> K3 greedy grouping
+-> poses copied to pinned host memory.  Steps are software-pipelined one deep (the host picks
+up batch i-1's poses after queueing batch i), all GPU work is in order on one stream.
+
+Random-init networks emit ~constant maps (no keypoints), which would leave the decoder with
+nothing to do; as SURVEY.md section 8(d) prescribes, synthetic GT-like stride-4 maps (4-20
+stick-figure persons per image, encoder conventions, noise) are ADDED to the head outputs inside
+the timed region, so the decoder sees a realistic candidate load and still depends on the
+backbone's result.
+
+Prints ONE JSON line (rank 0) with the driver's keys plus `roofline` (K1, the HBM-bound
+hand-written kernel, timed live with HIP events on the launch stream) and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+FLOP_PER_IMAGE = 732.78e9       # 2 x 366.39 GMAC, convs only, 640x640
+K1_BYTES_PER_IMAGE = 27_889_280  # 17*640*640*4 read + offset gathers + limbs write
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--flip', action='store_true', help='flip-test (BASELINE config 3): 2x images through the backbone')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    return ap.parse_args()
+
+
+def bench_init(model, seed):
+    """Variance-preserving random init: activations stay O(1) random data (all-zero / denormal
+    operands would let the chip clock higher than real inputs do)."""
+    g = torch.Generator().manual_seed(seed)
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Conv2d):
+            fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+            gain = 0.5 if name.endswith('conv2') else 1.0
+            m.weight.data.normal_(0, gain * (2.0 / fan_in) ** 0.5, generator=g)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+            m.running_mean.zero_()
+            m.running_var.fill_(1)
+    for head in model.headnets:  # heads: tiny outputs so the synthetic maps dominate the decoder input
+        for m in head.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.data.mul_(1e-4)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from offsetguided_amd import _lib, decoder, models, synth
+    from offsetguided_amd.config import coco_data as cd
+    _lib.load()
+
+    # ---- model + engine ----
+    p = argparse.ArgumentParser()
+    models.net_cli(p)
+    decoder.decoder_cli(p)
+    margs = p.parse_args(['--no-pretrain', '--topk', '32', '--thre-hmp', '0.04', '--person-thre', '0.04',
+                          '--dist-max', '40'])
+    margs.batch_size = a.batch
+    model, _ = models.model_factory(margs)
+    bench_init(model, 1234)
+    nb = a.batch * (2 if a.flip else 1)
+    engine = models.InferenceEngine(model, nb, a.size, a.size, dtype=torch.bfloat16, device=dev,
+                                    use_graph=not a.no_graph)
+    proc = decoder.decoder_factory(margs)
+
+    # ---- synthetic inputs, resident in HBM ----
+    n_rot = 3
+    images = [torch.randn(nb, 3, a.size, a.size, device=dev, generator=torch.Generator(dev).manual_seed(rank * 100 + r))
+              for r in range(n_rot)]
+    maps = []
+    for r in range(n_rot):
+        hm, off = synth.synth_batch(1000 * rank + r, a.batch, a.size, a.size, flip=a.flip)
+        maps.append((torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev), hm, off))
+
+    def features(i):
+        hm_o, off_o = engine.forward_raw(images[i % n_rot])
+        hm_s, off_s = maps[i % n_rot][0], maps[i % n_rot][1]
+        hm, off = hm_o + hm_s, off_o + off_s
+        return [([None, hm], [[], []], [[], []]), ([None, off], [[], []], [[], []])]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    def run_steps(n, first=0):
+        pending, out = None, None
+        for i in range(first, first + n):
+            nxt = proc.submit(features(i), flip_test=a.flip)
+            if pending is not None:
+                out = pending.result()
+            pending = nxt
+        out = pending.result()
+        torch.cuda.synchronize(dev)
+        return out
+
+    run_steps(max(a.warmup, 1))
+    barrier()
+    _lib.profile_start()
+    t0 = time.perf_counter()
+    poses = run_steps(a.steps, first=a.warmup)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_us = _lib.profile_stop()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- decoder-only and backbone-only timings (outside the headline region) ----
+    def timed(fn, n):
+        torch.cuda.synchronize(dev)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for i in range(n):
+            fn(i)
+        e.record()
+        torch.cuda.synchronize(dev)
+        return s.elapsed_time(e) / n  # ms
+
+    fixed = [[([None, m[0]], [[], []], [[], []]), ([None, m[1]], [[], []], [[], []])] for m in maps]
+    dec_ms = timed(lambda i: proc.limb_group.group_device(proc.generate_limbs(fixed[i % n_rot], flip_test=a.flip)), 20)
+    bb_ms = timed(lambda i: engine.forward_raw(images[i % n_rot]), 10)
+
+    # K1 on HBM-cold inputs: rotate hi-res heatmap batches whose total exceeds the 256 MiB Infinity Cache
+    hr = [decoder.factory.upsample4(m[0][:a.batch], 'bicubic') for m in maps]
+    _lib.profile_start()
+    for i in range(12):
+        proc.limb_collect.generate_limbs_lowres(hr[i % n_rot], maps[i % n_rot][1][:a.batch])
+    cold = _lib.profile_stop()
+
+    if rank == 0:
+        k1 = float(np.mean(stage_us['k1_nms_topk'])) + float(np.mean(stage_us['k2_collect']))
+        k1_cold = float(np.mean(cold['k1_nms_topk'][3:])) + float(np.mean(cold['k2_collect'][3:]))
+        k1_bytes = a.batch * K1_BYTES_PER_IMAGE * (a.size * a.size) / (640 * 640)
+        achieved = k1_bytes / (k1 * 1e-6) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'k1_traffic.json')
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+        imgs = a.batch * a.steps * world
+        line = {
+            'metric': 'images/sec end-to-end (backbone+decode) @640x640 bs8; decoder-only ms/img',
+            'value': round(imgs / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'bs{a.batch} {a.size}x{a.size}' + (' + flip-test' if a.flip else '') +
+                                   ': Hourglass-104+heads (bf16, HIP graph) -> HIP decoder topk=32, 17 heatmaps, 19 limbs'
+                                   ' (BASELINE configs[%d])' % (2 if a.flip else 1),
+                       'per_gpu_batch': a.batch, 'parallelism': f'batch-sharded x{world}, no collectives',
+                       'decoder_input': 'head outputs + synthetic GT-like maps'},
+            'decoder_ms_per_img': round(dec_ms / a.batch, 4),
+            'backbone_ms_per_batch': round(bb_ms, 3),
+            'backbone_tflops': round(nb * FLOP_PER_IMAGE * (a.size * a.size) / (640 * 640) / (bb_ms * 1e-3) / 1e12, 1),
+            'poses_last_batch': [int(len(x)) for x in poses],
+            'stage_us': {k: round(float(np.mean(v)), 2) for k, v in stage_us.items()},
+            'roofline': {'kernel': 'K1 = og_nms_topk_f32 (band_topk_kernel + merge_bands_kernel) + og_collect_limbs_f32',
+                         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'us_per_launch': round(k1, 2), 'algorithmic_bytes_per_launch': int(k1_bytes),
+                         'hbm_cold': {'us_per_launch': round(k1_cold, 2),
+                                      'achieved': round(k1_bytes / (k1_cold * 1e-6) / 1e9, 1),
+                                      'frac': round(k1_bytes / (k1_cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}},
+            'roofline_backbone': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS,
+                                  'achieved': round(nb * FLOP_PER_IMAGE / (bb_ms * 1e-3) / 1e12, 1),
+                                  'frac': round(nb * FLOP_PER_IMAGE / (bb_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import backbone_cpu
+            flags = dict(topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04, dist_max=40.0)
+            if a.flip:
+                perm, rev = cd.offset_hflip(cd.COCO_KEYPOINTS, cd.COCO_PERSON_SKELETON)
+                flags['flip'] = (cd.heatmap_hflip(cd.COCO_KEYPOINTS), perm, rev)
+            hm_np, off_np = maps[0][2], maps[0][3]
+            if a.flip:  # decode image pairs (i, i + batch)
+                sel = [0, a.batch]
+                hm_np, off_np = hm_np[sel], off_np[sel]
+            c = backbone_cpu.time_end_to_end(model, hm_np, off_np, cd.COCO_PERSON_SKELETON, a.size, flags)
+            per_img = c['backbone_s_per_img'] * (2 if a.flip else 1) + c['decode_s_per_img']
+            line['cpu_baseline'] = {
+                'value': round(1.0 / per_img, 4), 'unit': 'images/sec', 'cores': c['cores'], 'kind': 'port',
+                'sample': f"1 image through the eager fp32 PyTorch backbone on {c['cores']} threads "
+                          f"({c['backbone_s_per_img']:.2f} s) + {c['n_decode']} image(s) through the C oracle decoder, "
+                          f"1 thread ({c['decode_s_per_img'] * 1e3:.1f} ms/img)",
+                'decoder_ms_per_img': round(c['decode_s_per_img'] * 1e3, 2)}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -108,3 +108,40 @@ def int_table(values, device):
         t = torch.tensor(key[0], dtype=torch.int32, device=device)
         _const_cache[key] = t
     return t
+
+
+# ---- optional per-stage device timing (bench.py) -------------------------------------------
+_profile = None  # dict name -> list of (start_event, end_event) while enabled
+
+
+class stage_timer:
+    """`with stage_timer('nms_topk', device):` records HIP events on the launch stream when
+    profiling is enabled (profile_start()); free otherwise."""
+
+    def __init__(self, name, device):
+        self.name, self.device = name, device
+
+    def __enter__(self):
+        if _profile is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if _profile is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(self.device))
+            _profile.setdefault(self.name, []).append((self.start, end))
+
+
+def profile_start():
+    global _profile
+    _profile = {}
+
+
+def profile_stop():
+    """-> {stage: [durations in microseconds]} (synchronises)."""
+    global _profile
+    torch.cuda.synchronize()
+    out = {k: [a.elapsed_time(b) * 1e3 for a, b in v] for k, v in (_profile or {}).items()}
+    _profile = None
+    return out

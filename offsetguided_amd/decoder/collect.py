@@ -5,7 +5,7 @@ import torch
 
 from .. import _lib
 from ..config.coco_data import COCO_KEYPOINTS, COCO_PERSON_SKELETON
-from .heatmap import joint_dets
+from .heatmap import nms_topk_raw
 
 LOG = logging.getLogger(__name__)
 
@@ -70,13 +70,15 @@ class LimbsCollect(object):
         n, c, h, w = hmps_hr.shape
         n_limbs = len(self.skeleton)
         assert offs.shape[1] == 2 * n_limbs, 'offset channels must be 2 x number of limbs'
-        scores, inds, _, _ = joint_dets(hmps_hr, self.K)
         dev = hmps_hr.device
         lib = _lib.load()
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
-        _lib.check(lib.og_collect_limbs_f32(
-            _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,
-            _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
-            n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
-            _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)
+        with _lib.stage_timer('k1_nms_topk', dev):
+            scores, inds = nms_topk_raw(hmps_hr, self.K)
+        with _lib.stage_timer('k2_collect', dev):
+            _lib.check(lib.og_collect_limbs_f32(
+                _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,
+                _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
+                n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
+                _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)
         return limbs

@@ -31,8 +31,29 @@ def upsample4(x, mode):
     n, c, h, w = x.shape
     out = torch.empty((n, c, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
     fn = {'bicubic': lib.og_upsample_bicubic4_f32, 'bilinear': lib.og_upsample_bilinear4_f32}[mode]
-    _lib.check(fn(_lib.ptr(x), n * c, h, w, _lib.ptr(out), _lib.stream_ptr(x.device)), lib)
+    with _lib.stage_timer('k1a_upsample', x.device):
+        _lib.check(fn(_lib.ptr(x), n * c, h, w, _lib.ptr(out), _lib.stream_ptr(x.device)), lib)
     return out
+
+
+class PendingPoses:
+    """Result handle of PostProcess.submit(): the decode is queued on the stream, the finished
+    poses travel to pinned host memory asynchronously; result() waits for that copy only."""
+
+    def __init__(self, proc, limbs, poses, meta, host_poses, host_meta, event):
+        self._proc, self._limbs = proc, limbs
+        self._poses, self._meta = poses, meta
+        self._host_poses, self._host_meta, self._event = host_poses, host_meta, event
+
+    def result(self):
+        self._event.synchronize()
+        n = self._limbs.shape[0]
+        meta = self._host_meta.numpy()
+        counts, status = meta[:n], meta[n:]
+        if status.any():  # partial-skeleton table overflowed (rare): redo with a larger table
+            return self._proc.limb_group.group_batch(self._limbs)
+        host = self._host_poses.numpy()
+        return [host[i, :counts[i]].copy() for i in range(n)]
 
 
 class PostProcess(torch.nn.Module):
@@ -60,6 +81,7 @@ class PostProcess(torch.nn.Module):
         self.keypoints_flips = config.heatmap_hflip(keypoints)
         self.limbs_flips = config.offset_hflip(keypoints, skeleton)
         self.worker_pool = None  # grouping runs on the device; kept as an attribute for API parity
+        self._pinned, self._flip = {}, 0
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
                  'device-resident grouping', feat_stage, hmp_index, omp_index, inter_mode)
 
@@ -67,6 +89,24 @@ class PostProcess(torch.nn.Module):
     def generate_poses(self, features, flip_test=False, cat_flip_offs=False, scored_off=False):
         limbs = self.generate_limbs(features, flip_test, cat_flip_offs, scored_off)
         return self.limb_group.group_batch(limbs)
+
+    def submit(self, features, flip_test=False, cat_flip_offs=False, scored_off=False):
+        """Asynchronous generate_poses: returns a PendingPoses; call .result() later.  Lets the
+        caller queue the next batch's backbone before blocking on this batch's poses."""
+        limbs = self.generate_limbs(features, flip_test, cat_flip_offs, scored_off)
+        poses, meta = self.limb_group.group_device(limbs)
+        slot = self._pinned.get(tuple(poses.shape))
+        if slot is None:
+            slot = [[torch.empty(poses.shape, dtype=torch.float32).pin_memory(),
+                     torch.empty(meta.shape, dtype=torch.int32).pin_memory()] for _ in range(2)]
+            self._pinned[tuple(poses.shape)] = slot
+        self._flip = 1 - self._flip
+        host_poses, host_meta = slot[self._flip]
+        host_poses.copy_(poses, non_blocking=True)
+        host_meta.copy_(meta, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(poses.device))
+        return PendingPoses(self, limbs, poses, meta, host_poses, host_meta, event)
 
     def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
         """Merge the predictions for [images, mirrored images] (decoder/factory.py:98-146)."""
@@ -84,10 +124,12 @@ class PostProcess(torch.nn.Module):
         keep = [1 if l in self.limbs_flips[1] else 0 for l in range(n_limbs)]
         hm_out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
         off_out = torch.empty((n, 2 * n_limbs, h, w), dtype=torch.float32, device=dev)
-        _lib.check(lib.og_flip_merge_f32(
-            _lib.ptr(hmps), _lib.ptr(offs), n, c, n_limbs, h, w,
-            _lib.ptr(_lib.int_table(self.keypoints_flips, dev)), _lib.ptr(_lib.int_table(self.limbs_flips[0], dev)),
-            _lib.ptr(_lib.int_table(keep, dev)), _lib.ptr(hm_out), _lib.ptr(off_out), _lib.stream_ptr(dev)), lib)
+        with _lib.stage_timer('k0_flip_merge', dev):
+            _lib.check(lib.og_flip_merge_f32(
+                _lib.ptr(hmps), _lib.ptr(offs), n, c, n_limbs, h, w,
+                _lib.ptr(_lib.int_table(self.keypoints_flips, dev)),
+                _lib.ptr(_lib.int_table(self.limbs_flips[0], dev)),
+                _lib.ptr(_lib.int_table(keep, dev)), _lib.ptr(hm_out), _lib.ptr(off_out), _lib.stream_ptr(dev)), lib)
         return hm_out, jomps, off_out, scmps, vector_nd
 
     # ---- device-resident pieces ----------------------------------------------------------

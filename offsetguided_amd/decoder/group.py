@@ -67,11 +67,12 @@ class GreedyGroup(object):
         meta = torch.empty(2 * n, dtype=torch.int32, device=dev)
         nbytes = lib.og_group_workspace_bytes(n, self.n_keypoints, mmax)
         ws = _lib.workspace(dev, nbytes, 'group')
-        _lib.check(lib.og_greedy_group_f32(
-            _lib.ptr(limbs), n, n_limbs, k, _lib.ptr(jf), _lib.ptr(jt), self.n_keypoints,
-            float(self.person_thre), float(self.dist_max), int(bool(self.use_scale)), int(self.sort_dim),
-            mmax, _lib.ptr(poses), _lib.ptr(meta), _lib.ptr(meta[n:]), _lib.ptr(ws), ws.numel(),
-            _lib.stream_ptr(dev)), lib)
+        with _lib.stage_timer('k3_group', dev):
+            _lib.check(lib.og_greedy_group_f32(
+                _lib.ptr(limbs), n, n_limbs, k, _lib.ptr(jf), _lib.ptr(jt), self.n_keypoints,
+                float(self.person_thre), float(self.dist_max), int(bool(self.use_scale)), int(self.sort_dim),
+                mmax, _lib.ptr(poses), _lib.ptr(meta), _lib.ptr(meta[n:]), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev)), lib)
         return poses, meta
 
 

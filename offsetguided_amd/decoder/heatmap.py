@@ -28,6 +28,17 @@ def hmp_NMS(heat, kernel=3):
 
 
 def _topk(entry, scores, K):
+    out_s, out_i = _topk_raw(entry, scores, K)
+    w = scores.shape[-1]
+    return out_s, out_i, torch.div(out_i, w, rounding_mode='floor'), out_i % w
+
+
+def nms_topk_raw(hmps, k):
+    """joint_dets without the derived ys/xs tensors: (scores, flat idx), each (N, C, k)."""
+    return _topk_raw("og_nms_topk_f32", hmps, k)
+
+
+def _topk_raw(entry, scores, K):
     scores = _lib.require_device(scores, "scores")
     lib = _lib.load()
     n, c, h, w = scores.shape
@@ -41,7 +52,7 @@ def _topk(entry, scores, K):
     fn = getattr(lib, entry)
     _lib.check(fn(_lib.ptr(scores), n * c, h, w, K, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(ws), ws.numel(),
                   _lib.stream_ptr(dev)), lib)
-    return out_s, out_i, torch.div(out_i, w, rounding_mode='floor'), out_i % w
+    return out_s, out_i
 
 
 def topK_channel(scores, K=40):

@@ -1,0 +1,154 @@
+"""MI355X inference engine for NetworkWrapper(Hourglass104 + hmp/omp heads).
+
+The dense convolutions stay on PyTorch-ROCm (MIOpen -> MFMA); what this file adds is the shape
+the hardware wants:
+  * every BatchNorm folded into the preceding convolution (160 BN layers disappear);
+  * bf16 activations/weights in channels-last (NHWC) layout, fp32 accumulation inside MIOpen;
+  * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only);
+  * the whole forward (~500 launches, tiny 5x5..20x20 tiles deep in the hourglass) is captured
+    once into a HIP graph and replayed: launch latency, not math, bounds the deep levels;
+  * head outputs leave as dense fp32 NCHW tensors, the layout the HIP decoder kernels stream.
+The result keeps the reference nesting [ (hmps[S], bg[S], jo[S]), (offs[S], spreads[S], scales[S]) ]
+(models/networks.py:189-194); stacks that are not decoded hold None.
+"""
+import torch
+import torch.nn.functional as F
+
+from .hourglass_104 import ConvBlock, HourglassLevel, Residual
+
+
+def _fold(conv, bn):
+    """conv (+ optional BatchNorm in eval mode) -> (weight, bias) fp32."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if isinstance(bn, torch.nn.BatchNorm2d):
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * scale[:, None, None, None]
+        b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+    return w, b
+
+
+class _Conv:
+    __slots__ = ('w', 'b', 'stride', 'pad', 'relu')
+
+    def __init__(self, conv, bn, relu, dtype):
+        w, b = _fold(conv, bn)
+        self.w = w.to(dtype).contiguous(memory_format=torch.channels_last)
+        self.b = b.to(dtype)
+        self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
+
+    def __call__(self, x):
+        y = F.conv2d(x, self.w, self.b, self.stride, self.pad)
+        return F.relu_(y) if self.relu else y
+
+
+class _Residual:
+    def __init__(self, m, dtype):
+        self.c1 = _Conv(m.conv1, m.bn1, True, dtype)
+        self.c2 = _Conv(m.conv2, m.bn2, False, dtype)
+        self.skip = _Conv(m.skip[0], m.skip[1], False, dtype) if len(m.skip) else None
+
+    def __call__(self, x):
+        y = self.c2(self.c1(x))
+        y += x if self.skip is None else self.skip(x)
+        return F.relu_(y)
+
+
+def _seq(mods, dtype):
+    return [_Residual(m, dtype) for m in mods]
+
+
+def _run(seq, x):
+    for f in seq:
+        x = f(x)
+    return x
+
+
+class _Level:
+    def __init__(self, m, dtype):
+        self.up1, self.low1, self.low3 = _seq(m.up1, dtype), _seq(m.low1, dtype), _seq(m.low3, dtype)
+        self.low2 = _Level(m.low2, dtype) if isinstance(m.low2, HourglassLevel) else _seq(m.low2, dtype)
+
+    def __call__(self, x):
+        low = _run(self.low1, x)
+        low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
+        low = _run(self.low3, low)
+        up = _run(self.up1, x)
+        up += F.interpolate(low, scale_factor=2, mode='nearest')
+        return up
+
+
+class InferenceEngine:
+    """engine = InferenceEngine(model, batch, H, W); feats = engine(images)  (images fp32 NCHW on device).
+
+    `batch` is the number of images per call (2x the evaluation batch with flip-test)."""
+
+    def __init__(self, model, batch, height, width, dtype=torch.bfloat16, device='cuda:0', feat_stage=-1,
+                 use_graph=True):
+        assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.shape = (batch, 3, height, width)
+        net = model.basenet
+        self.n_stacks = net.nstack
+        self.stage = feat_stage % self.n_stacks
+        dev_model = model.to(self.device).eval()
+        net = dev_model.basenet
+        assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
+        self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype), _Residual(net.pre[1], dtype)]
+        self.kps = [_Level(net.kps[s], dtype) for s in range(self.stage + 1)]
+        self.cnvs = [_Conv(net.cnvs[s].conv, net.cnvs[s].bn, True, dtype) for s in range(self.stage + 1)]
+        self.inters = [_Residual(net.inters[s], dtype) for s in range(self.stage)]
+        self.inters_ = [_Conv(net.inters_[s][0], net.inters_[s][1], False, dtype) for s in range(self.stage)]
+        self.cnvs_ = [_Conv(net.cnvs_[s][0], net.cnvs_[s][1], False, dtype) for s in range(self.stage)]
+        hm_head, off_head = dev_model.headnets[0], dev_model.headnets[1]
+        self.hm = _Conv(hm_head.hp_convs[self.stage], None, False, dtype)
+        self.off = _Conv(off_head.reg_convs[self.stage], None, False, dtype)
+        self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+        self._graph = None
+        self._out = None
+        if use_graph:
+            self._capture()
+
+    def _forward(self, images):
+        x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        inter = _run(self.pre, x)
+        feat = None
+        for s in range(self.stage + 1):
+            feat = self.cnvs[s](self.kps[s](inter))
+            if s < self.stage:
+                mix = self.inters_[s](inter)
+                mix += self.cnvs_[s](feat)
+                inter = self.inters[s](F.relu_(mix))
+        hm = self.hm(feat).float().contiguous(memory_format=torch.contiguous_format)
+        off = self.off(feat).float().contiguous(memory_format=torch.contiguous_format)
+        return hm, off
+
+    def _capture(self):
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                      # warm-up: MIOpen kernel selection, allocator
+                self._forward(self._static_in)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._out = self._forward(self._static_in)
+
+    @torch.no_grad()
+    def forward_raw(self, images):
+        """(hm (N,17,h,w), off (N,38,h,w)) fp32 NCHW; graph outputs are reused by the next call."""
+        assert tuple(images.shape) == self.shape, f'engine built for {self.shape}, got {tuple(images.shape)}'
+        if self._graph is None:
+            return self._forward(images.to(self.device))
+        self._static_in.copy_(images, non_blocking=True)
+        self._graph.replay()
+        return self._out
+
+    def __call__(self, images):
+        hm, off = self.forward_raw(images)
+        hms, offs = [None] * self.n_stacks, [None] * self.n_stacks
+        hms[self.stage], offs[self.stage] = hm, off
+        empty = [[] for _ in range(self.n_stacks)]
+        return [(hms, list(empty), list(empty)), (offs, list(empty), list(empty))]
