@@ -10,41 +10,36 @@
 //   panel.  A lane owns VEC consecutive columns (float4 when W % 4 == 0) and walks down the
 //   band keeping a 3-row window of horizontal maxima in registers; left/right neighbours come
 //   from the adjacent lanes by DPP wave shifts, so a panel is 62 interior lanes + 2 halo
-//   lanes and no LDS or extra loads are needed for the stencil.  Rows are prefetched
-//   PREFETCH deep (16 B/lane each) to keep >= 64 KiB in flight per CU.
+//   lanes and no LDS or extra loads are needed for the stencil.
+//   Loads are buffer loads through a per-plane descriptor: rows above/below the plane and
+//   lanes left/right of it get an out-of-range offset and read as 0.0 -- exactly the zero
+//   padding of F.pad -- with no branch and no select, so the compiler keeps PREFETCH rows
+//   (16 B/lane each) in flight with counted vmcnt waits.  The kernel is instruction-issue
+//   sensitive (not just HBM-bound), hence the diet: one integer compare implements
+//   "v > 0 and v >= tau" (positive floats order like their bit patterns) and halo/idle lanes
+//   carry tau = INT_MAX instead of a separate mask.
 //   Candidates (positive 3x3 peaks, or every pixel in plain top-k mode) are compacted with
-//   ballot + popcount into a per-wave LDS segment; when a segment fills, the wave keeps its
-//   own top-k (rank-by-counting on order-preserving 64-bit keys) and raises its admission
-//   threshold, so the result is exact for any input.  Each band emits its k best keys; a
-//   second tiny kernel (one wave per plane) k-way merges the bands and writes scores/indices.
+//   the compare masks themselves (they are the ballots) + mbcnt into a per-wave LDS segment;
+//   when a segment fills, the wave keeps its own top-k (rank-by-counting on order-preserving
+//   64-bit keys, ping-pong buffers) and raises its admission threshold, so the result is
+//   exact for any input.  Each band emits its k best keys; a second tiny kernel (one wave per
+//   plane) selects the plane's top-k from the band lists and writes scores/indices.
 #include <math.h>
 
 #include "og_common.h"
 
 namespace {
 
-constexpr int kPrefetch = 8;      // rows in flight per lane
+constexpr int kPrefetch = 4;      // rows in flight per lane
 constexpr int kInterior = 62;     // interior lanes per wave panel
 constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
+constexpr uint32_t kLaneOob = 0x80000000u;  // offset of lanes outside the image
+constexpr uint32_t kRowOob = 0x40000000u;   // offset of rows the band must not read
 
 template <int VEC>
 struct Px {
     float c[VEC];
 };
-
-template <int VEC>
-__device__ __forceinline__ Px<VEC> load_px(const float *p, bool ok)
-{
-    Px<VEC> r;
-    if constexpr (VEC == 4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) t = *reinterpret_cast<const float4 *>(p);
-        r.c[0] = t.x; r.c[1] = t.y; r.c[2] = t.z; r.c[3] = t.w;
-    } else {
-        r.c[0] = ok ? *p : 0.f;
-    }
-    return r;
-}
 
 // horizontal 3-max of one row; neighbours of the edge components come from adjacent lanes
 template <int VEC>
@@ -66,30 +61,43 @@ struct TileGeom {
     int plane_rows, plane_cols;  // H, W
     int r0, r1;                  // interior rows [r0, r1)
     int col;                     // first column of this lane (may be < 0 or >= W: halo / idle)
-    bool loads;                  // lane reads memory (interior or halo lane inside the image)
+    uint32_t lane_off;           // byte offset of the lane's strip inside a row, or kLaneOob
     bool interior;               // lane emits results
 };
 
 // Walk rows r0..r1-1 of one panel; emit(row, centre values, 3x3 max incl. zero padding).
-template <int VEC, class Emit>
-__device__ __forceinline__ void walk_panel(const float *__restrict__ plane, const TileGeom &g, Emit &&emit)
+template <int VEC, int PF, class Emit>
+__device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g, Emit &&emit)
 {
     const int H = g.plane_rows, W = g.plane_cols;
+    const uint32_t row_bytes = (uint32_t)W * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(plane), 0, (int)((uint32_t)H * row_bytes), 0x00020000);
     auto load_row = [&](int row) {
-        const bool ok = g.loads && row >= 0 && row < H && row <= g.r1;
-        return load_px<VEC>(plane + (size_t)(ok ? row : 0) * W + (ok ? g.col : 0), ok);
+        // row -1 wraps to a huge offset, rows past the band's halo get kRowOob: both read as zeros
+        const uint32_t srow = (row <= g.r1) ? (uint32_t)row * row_bytes : kRowOob;
+        const int off = (int)(g.lane_off + srow);
+        Px<VEC> r;
+        if constexpr (VEC == 4) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            r.c[0] = t.x; r.c[1] = t.y; r.c[2] = t.z; r.c[3] = t.w;
+        } else {
+            r.c[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        }
+        return r;
     };
     Px<VEC> hm_a = hmax3<VEC>(load_row(g.r0 - 1));
     Px<VEC> v_b = load_row(g.r0);
     Px<VEC> hm_b = hmax3<VEC>(v_b);
-    Px<VEC> q[kPrefetch];
+    Px<VEC> q[PF];
 #pragma unroll
-    for (int u = 0; u < kPrefetch; ++u) q[u] = load_row(g.r0 + 1 + u);
-    for (int r = g.r0; r < g.r1; r += kPrefetch) {
+    for (int u = 0; u < PF; ++u) q[u] = load_row(g.r0 + 1 + u);
+    for (int r = g.r0; r < g.r1; r += PF) {
 #pragma unroll
-        for (int u = 0; u < kPrefetch; ++u) {
+        for (int u = 0; u < PF; ++u) {
             const Px<VEC> v_c = q[u];
-            q[u] = load_row(r + u + 1 + kPrefetch);
+            q[u] = load_row(r + u + 1 + PF);
             const Px<VEC> hm_c = hmax3<VEC>(v_c);  // all lanes take part in the DPP shifts
             if (r + u < g.r1) {
                 Px<VEC> m;
@@ -118,7 +126,8 @@ __device__ __forceinline__ TileGeom make_geom(int H, int W, int rows, int band, 
     g.r1 = min(g.r0 + rows, H);
     g.col = s * vec;
     g.interior = lane >= 1 && lane <= s_cnt;
-    g.loads = lane <= s_cnt + 1 && s >= 0 && s < strips;
+    const bool loads = lane <= s_cnt + 1 && s >= 0 && s < strips;
+    g.lane_off = loads ? (uint32_t)g.col * 4u : kLaneOob;
     return g;
 }
 
@@ -136,7 +145,7 @@ nms_map_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int
     const TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
     const float *src = in + (size_t)plane * H * W;
     float *dst = out + (size_t)plane * H * W;
-    walk_panel<VEC>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
+    walk_panel<VEC, kPrefetch>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
         if (!g.interior) return;
         float o[VEC];
 #pragma unroll
@@ -150,63 +159,62 @@ nms_map_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int
 // ---------------------------------------------------------------------------------------
 // band kernel: stream + candidate compaction + per-band top-k
 // ---------------------------------------------------------------------------------------
-// Per-wave candidate segment in LDS.  KPL = keys per lane during a compaction, capacity
-// 64*KPL; a compaction leaves <= k keys, so k + 64 <= capacity is required.
-template <int KPL>
+// Per-wave candidate segment in LDS: two buffers of `cap` keys (ping-pong).  A compaction
+// leaves <= k keys sorted descending, so k + 64 <= cap is required.
 struct WaveSeg {
-    uint64_t *keys;  // LDS, 64*KPL entries
-    int cnt;         // wave-uniform
-    float tau;       // admit v >= tau (wave-uniform)
+    uint64_t *cur, *alt;  // LDS
+    int cap;
+    int cnt;              // wave-uniform
+    // admission threshold: NMS mode compares float bit patterns as signed ints (>= 1 means
+    // strictly positive), plain mode compares floats
+    int tau_bits;
+    float tau_f;
 
-    // Keep the k largest keys, sorted descending, in keys[0..min(cnt,k)).
+    __device__ __forceinline__ void set_tau(float t)
+    {
+        tau_f = t;
+        tau_bits = __builtin_bit_cast(int, t);
+    }
+
+    // Keep the k largest keys, sorted descending, in cur[0..min(cnt,k)).
     __device__ __forceinline__ void compact(int k)
     {
         const int lane = threadIdx.x & 63;
-        uint64_t mine[KPL];
-        int rank[KPL];
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) {
-            const int p = lane + 64 * i;
-            mine[i] = (p < cnt) ? keys[p] : 0ull;
-            rank[i] = 0;
-        }
-        for (int j = 0; j < cnt; ++j) {
-            const uint64_t o = keys[j];  // LDS broadcast
-#pragma unroll
-            for (int i = 0; i < KPL; ++i) rank[i] += (o > mine[i]);
+        for (int i = lane; i < cnt; i += 64) {
+            const uint64_t mine = cur[i];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += (cur[j] > mine);  // LDS broadcast reads
+            if (rank < k) alt[rank] = mine;
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < KPL; ++i)
-            if (lane + 64 * i < cnt && rank[i] < k) keys[rank[i]] = mine[i];
-        __builtin_amdgcn_wave_barrier();
+        uint64_t *t = cur; cur = alt; alt = t;
         if (cnt >= k) {
             cnt = k;
-            tau = og_key_value(keys[k - 1]);
+            set_tau(og_key_value(cur[k - 1]));
         }
     }
 
-    __device__ __forceinline__ void push(bool pred, uint64_t key, int k)
+    // `mask` = lanes whose candidate passes (it is the ballot of the compare)
+    __device__ __forceinline__ void push(uint64_t mask, float v, uint32_t idx, int k)
     {
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(pred);
         if (mask == 0) return;
         const int n = __builtin_popcountll(mask);
-        if (cnt + n > 64 * KPL) compact(k);
+        if (cnt + n > cap) compact(k);
+        const int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
         const int lane = threadIdx.x & 63;
-        const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (pred) keys[pos] = key;
+        if ((mask >> lane) & 1ull) cur[pos] = og_make_key(v, idx);
         cnt += n;
     }
 };
 
-// NMS_MODE: candidates are strictly positive 3x3 peaks (zero padding); otherwise every pixel.
-template <int VEC, int KPL, bool NMS_MODE>
+template <int VEC, bool NMS_MODE, int PF>
 __global__ void __launch_bounds__(64 * kMaxWaves)
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
-                 int H, int W, int k, int rows, int nbands, int panel_strips, int total, int padded)
+                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded)
 {
     extern __shared__ uint64_t smem[];
     __shared__ int s_cnt[kMaxWaves];
+    __shared__ uint64_t *s_list[kMaxWaves];
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
     const int plane = wid / nbands, band = wid % nbands;
@@ -214,31 +222,48 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     const TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
     const float *src = in + (size_t)plane * H * W;
 
-    WaveSeg<KPL> seg;
-    seg.keys = smem + (size_t)wave * 64 * KPL;
+    WaveSeg seg;
+    seg.cur = smem + (size_t)wave * 2 * cap;
+    seg.alt = seg.cur + cap;
+    seg.cap = cap;
     seg.cnt = 0;
-    seg.tau = NMS_MODE ? 0.f : -INFINITY;
+    if (NMS_MODE) { seg.tau_bits = 1; seg.tau_f = 0.f; }  // bits >= 1  <=>  v > +0
+    else seg.set_tau(-INFINITY);
 
-    walk_panel<VEC>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
-        bool pred[VEC];
-        bool any = false;
+    walk_panel<VEC, PF>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
+        uint64_t mk[VEC];
+        uint64_t any = 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const bool inimg = g.interior && (g.col + j < W);
-            pred[j] = NMS_MODE ? (inimg && v.c[j] > 0.f && v.c[j] == m.c[j] && v.c[j] >= seg.tau)
-                               : (inimg && v.c[j] >= seg.tau);
-            any |= pred[j];
+            bool p;
+            const bool emits = g.interior && (VEC == 4 || g.col + j < W);
+            if (NMS_MODE) {
+                const int lane_tau = emits ? seg.tau_bits : 0x7fffffff;
+                p = (__builtin_bit_cast(int, v.c[j]) >= lane_tau) && (v.c[j] == m.c[j]);
+            } else {
+                const float lane_tau = emits ? seg.tau_f : INFINITY;
+                p = v.c[j] >= lane_tau;
+            }
+            mk[j] = __builtin_amdgcn_ballot_w64(p);
+            any |= mk[j];
         }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0ull, 0)) {
+        if (__builtin_expect(any != 0ull, 0)) {
             const uint32_t base = (uint32_t)row * (uint32_t)W + (uint32_t)g.col;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) seg.push(pred[j] && v.c[j] >= seg.tau, og_make_key(v.c[j], base + j), k);
+            for (int j = 0; j < VEC; ++j) {
+                uint64_t mj = mk[j];
+                if (j > 0) {  // an earlier component may have raised tau: re-test
+                    const bool p = NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.tau_bits) : (v.c[j] >= seg.tau_f);
+                    mj &= __builtin_amdgcn_ballot_w64(p);
+                }
+                seg.push(mj, v.c[j], base + j, k);
+            }
         }
     });
 
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
-    if ((threadIdx.x & 63) == 0) s_cnt[wave] = min(seg.cnt, k);
+    if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_list[wave] = seg.cur; }
     __syncthreads();
     int total_keys = 0;
     for (int w = 0; w < nwaves; ++w) total_keys += s_cnt[w];
@@ -246,10 +271,10 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     for (int t = threadIdx.x; t < total_keys; t += blockDim.x) {
         int w = 0, o = t;
         while (o >= s_cnt[w]) { o -= s_cnt[w]; ++w; }
-        const uint64_t key = smem[(size_t)w * 64 * KPL + o];
+        const uint64_t key = s_list[w][o];
         int rank = 0;
         for (int w2 = 0; w2 < nwaves; ++w2) {
-            const uint64_t *kk = smem + (size_t)w2 * 64 * KPL;
+            const uint64_t *kk = s_list[w2];
             const int c2 = s_cnt[w2];
             for (int j = 0; j < c2; ++j) rank += (kk[j] > key);
         }
@@ -259,67 +284,68 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 }
 
 // ---------------------------------------------------------------------------------------
-// merge kernel: one wave per plane, k-way tournament over the (sorted) band lists
+// merge kernel: one wave per plane selects the plane's top-k from the sorted band lists.
+//   A) a lower bound L on the k-th best: the k-th largest among the first `t` keys of every
+//      band (a subset of all keys, so the true k-th best is >= L);
+//   B) compact the keys >= L (usually just over k of them);
+//   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, off);
-        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off);
-        const uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
 template <bool NMS_MODE>
 __global__ void __launch_bounds__(64)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
-                   const float *__restrict__ in, int H, int W, int k, int nbands,
+                   const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
                    float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
 {
-    extern __shared__ uint64_t skeys[];  // nbands * k (when it fits) else unused
+    extern __shared__ uint64_t lds64[];
     const int plane = blockIdx.x, lane = threadIdx.x;
-    const uint64_t *gk = band_keys + (size_t)plane * nbands * k;
+    const int n_all = nbands * k;
+    uint64_t *all = lds64;             // n_all keys (0 = empty slot)
+    uint64_t *flt = lds64 + n_all;     // filtered keys
+    __shared__ uint64_t s_bound;
+    __shared__ int s_cnts[256];
+    const uint64_t *gk = band_keys + (size_t)plane * n_all;
     const int *gc = band_cnt + (size_t)plane * nbands;
     float *os = out_scores + (size_t)plane * k;
     int64_t *oi = out_inds + (size_t)plane * k;
 
-    // stage the valid prefix of every band list in LDS (bands beyond 64 are folded per lane)
-    for (int b = 0; b < nbands; ++b) {
-        const int c = gc[b];
-        for (int j = lane; j < c; j += 64) skeys[(size_t)b * k + j] = gk[(size_t)b * k + j];
+    for (int b = lane; b < nbands; b += 64) s_cnts[b] = gc[b];
+    if (lane == 0) s_bound = 0ull;
+    __syncthreads();
+    for (int i = lane; i < n_all; i += 64) all[i] = (i % k < s_cnts[i / k]) ? gk[i] : 0ull;
+    __syncthreads();
+    // A) k-th largest of the subset {first t_sub keys of each band}
+    const int n_sub = nbands * t_sub;
+    for (int i = lane; i < n_sub; i += 64) {
+        const uint64_t mine = all[(i / t_sub) * k + i % t_sub];
+        if (mine == 0ull) continue;
+        int rank = 0;
+        for (int j = 0; j < n_sub; ++j) rank += (all[(j / t_sub) * k + j % t_sub] > mine);
+        if (rank == k - 1) s_bound = mine;
     }
-    __builtin_amdgcn_wave_barrier();
-    // lane owns bands lane, lane+64, ...; ptr = how many keys it has consumed from each
-    constexpr int kFold = 4;  // up to 256 bands
-    int ptr[kFold], cnt[kFold];
-#pragma unroll
-    for (int f = 0; f < kFold; ++f) {
-        const int b = lane + 64 * f;
-        ptr[f] = 0;
-        cnt[f] = (b < nbands) ? gc[b] : 0;
+    __syncthreads();
+    const uint64_t bound = s_bound;
+    // B) keys >= bound
+    int nf = 0;
+    for (int i0 = 0; i0 < n_all; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t key = (i < n_all) ? all[i] : 0ull;
+        const bool keep = key != 0ull && key >= bound;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) flt[nf + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
+        nf += __builtin_popcountll(mask);
     }
-    int t = 0;
-    for (; t < k; ++t) {
-        uint64_t best = 0ull;
-        int bf = 0;
-#pragma unroll
-        for (int f = 0; f < kFold; ++f) {
-            const int b = lane + 64 * f;
-            const uint64_t c = (ptr[f] < cnt[f]) ? skeys[(size_t)b * k + ptr[f]] : 0ull;
-            if (c > best) { best = c; bf = f; }
+    __syncthreads();
+    // C) rank and emit
+    for (int i = lane; i < nf; i += 64) {
+        const uint64_t mine = flt[i];
+        int rank = 0;
+        for (int j = 0; j < nf; ++j) rank += (flt[j] > mine);
+        if (rank < k) {
+            os[rank] = og_key_value(mine);
+            oi[rank] = (int64_t)og_key_index(mine);
         }
-        const uint64_t top = wave_max_u64(best);
-        if (top == 0ull) break;
-        if (best == top) {  // keys are unique: exactly one lane
-#pragma unroll
-            for (int f = 0; f < kFold; ++f) ptr[f] += (f == bf);
-            os[t] = og_key_value(top);
-            oi[t] = (int64_t)og_key_index(top);
-        }
     }
+    int t = min(nf, k);
     if (NMS_MODE && t < k) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
@@ -351,7 +377,7 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
 }
 
 struct Plan {
-    int vec, rows, nbands, panel_strips, nwaves, kpl;
+    int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;
     size_t keys_off, cnt_off, bytes;
 };
 
@@ -361,20 +387,22 @@ int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
-bool make_plan(long planes, int H, int W, int k, const void *base, Plan *p)
+bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
 {
-    p->vec = (W % 4 == 0 && ((uintptr_t)base % 16 == 0)) ? 4 : 1;
+    p->vec = (W % 4 == 0 && aligned16) ? 4 : 1;
     const int strips = (W + p->vec - 1) / p->vec;
     p->nwaves = (strips + kInterior - 1) / kInterior;
     if (p->nwaves > kMaxWaves) return false;
     p->panel_strips = (strips + p->nwaves - 1) / p->nwaves;
-    int rows = env_int("OG_NMS_ROWS", 32);
-    rows = max(rows, (H + 63) / 64);  // the merge wave folds at most 256 bands; keep it <= 64 normally
+    int rows = env_int("OG_NMS_ROWS", 40);
+    rows = max(rows, (H + 255) / 256);  // the merge kernel indexes at most 256 bands
     rows = min(rows, H);
     p->rows = rows;
     p->nbands = (H + rows - 1) / rows;
-    p->kpl = (k + 64 <= 256) ? 4 : 8;
-    if (k + 64 > 64 * p->kpl) return false;
+    p->cap = (2 * k + 64 + 63) / 64 * 64;
+    if ((size_t)p->nwaves * 2 * p->cap * sizeof(uint64_t) > 60 * 1024) return false;
+    // subset depth for the merge's lower bound: nbands * t_sub >= k whenever possible
+    p->t_sub = min(k, max(2, (k + p->nbands - 1) / p->nbands + 1));
     p->keys_off = 0;
     p->cnt_off = og_align_up((size_t)planes * p->nbands * k * sizeof(uint64_t), 256);
     p->bytes = p->cnt_off + og_align_up((size_t)planes * p->nbands * sizeof(int), 256);
@@ -388,15 +416,13 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_REQUIRE(in && out_scores && out_inds && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(planes > 0 && H > 0 && W > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE((long)H * W >= k, OG_EINVAL, "%s: selected index k out of range (k=%d > H*W=%ld)", name, k, (long)H * W);
-    OG_REQUIRE((long)H * W < (1l << 32), OG_EINVAL, "%s: plane too large", name);
+    OG_REQUIRE((long)H * W < (1l << 27), OG_EINVAL, "%s: plane too large", name);
     if (NMS_MODE) OG_REQUIRE(2l * (H + W) - 4 >= k, OG_EINVAL, "%s: plane border smaller than k", name);
     Plan p;
-    OG_REQUIRE(make_plan(planes, H, W, k, in, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d", name, W, k);
-    // planes must share the alignment decision
-    if (p.vec == 4 && ((size_t)H * W * sizeof(float)) % 16 != 0) p.vec = 1;
+    OG_REQUIRE(make_plan(planes, H, W, k, (uintptr_t)in % 16 == 0, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d",
+               name, W, k);
     OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
-    OG_REQUIRE(p.nbands <= 256, OG_EUNSUPPORTED, "%s: too many bands", name);
     uint64_t *keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
     int *cnts = reinterpret_cast<int *>((char *)workspace + p.cnt_off);
 
@@ -404,20 +430,18 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
     const dim3 block(64 * p.nwaves);
-    const size_t lds = (size_t)p.nwaves * 64 * p.kpl * sizeof(uint64_t);
-#define OG_BAND(VEC, KPL)                                                                                   \
-    hipLaunchKernelGGL((band_topk_kernel<VEC, KPL, NMS_MODE>), dim3(padded), block, lds, stream, in, keys, \
-                       cnts, H, W, k, p.rows, p.nbands, p.panel_strips, (int)total, padded)
-    if (p.vec == 4 && p.kpl == 4) OG_BAND(4, 4);
-    else if (p.vec == 4) OG_BAND(4, 8);
-    else if (p.kpl == 4) OG_BAND(1, 4);
-    else OG_BAND(1, 8);
-#undef OG_BAND
+    const size_t lds = (size_t)p.nwaves * 2 * p.cap * sizeof(uint64_t);
+    if (p.vec == 4)
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts, H,
+                           W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
+    else
+        hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts, H,
+                           W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
     OG_LAUNCH_CHECK(name);
-    const size_t mlds = (size_t)p.nbands * k * sizeof(uint64_t);
+    const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
     hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(64), mlds, stream, keys, cnts, in, H,
-                       W, k, p.nbands, out_scores, out_inds);
+                       W, k, p.nbands, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -428,7 +452,7 @@ OG_API size_t og_topk_workspace_bytes(long planes, int H, int W, int k)
 {
     Plan p;
     if (planes <= 0 || H <= 0 || W <= 0 || k <= 0) return 0;
-    if (!make_plan(planes, H, W, k, nullptr, &p)) return 0;
+    if (!make_plan(planes, H, W, k, true, &p)) return 0;
     return p.bytes;
 }
 
@@ -451,14 +475,10 @@ OG_API int og_hmp_nms_f32(const float *heat, long planes, int H, int W, float *o
     const char *name = "og_hmp_nms_f32";
     OG_REQUIRE(heat && out, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(planes > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE((long)H * W < (1l << 27), OG_EINVAL, "%s: plane too large", name);
     Plan p;
-    OG_REQUIRE(make_plan(planes, H, W, 1, heat, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d", name, W);
-    if ((uintptr_t)out % 16 != 0 || ((size_t)H * W * sizeof(float)) % 16 != 0) p.vec = 1;
-    if (p.vec == 1) {  // recompute the panel split for scalar lanes
-        p.nwaves = (W + kInterior - 1) / kInterior;
-        OG_REQUIRE(p.nwaves <= kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide for the unaligned path", name, W);
-        p.panel_strips = (W + p.nwaves - 1) / p.nwaves;
-    }
+    const bool aligned = (uintptr_t)heat % 16 == 0 && (uintptr_t)out % 16 == 0;
+    OG_REQUIRE(make_plan(planes, H, W, 1, aligned, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d", name, W);
     const long total = planes * p.nbands;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);

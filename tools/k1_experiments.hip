@@ -1,0 +1,97 @@
+// Tuning harness for K1 (not part of the product): includes the kernel TU directly so template
+// parameters (prefetch depth) and launch geometry (rows per band) can be swept in one run.
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I include -I offsetguided_amd/csrc \
+//         tools/k1_experiments.hip offsetguided_amd/csrc/abi.cpp -o /tmp/k1exp && /tmp/k1exp
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../offsetguided_amd/csrc/nms_topk.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(float *p, size_t n, uint32_t seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (float)(x >> 8) * (1.0f / 16777216.0f) - 0.3f;  // white noise: ~8% of pixels are positive peaks (worst case)
+    }
+}
+
+// streaming ceiling of the same access pattern: loads + stencil maxima, one store per lane at the end
+template <int PF>
+__global__ void __launch_bounds__(64 * kMaxWaves)
+stream_only_kernel(const float *__restrict__ in, float *__restrict__ sink, int H, int W, int rows, int nbands,
+                   int panel_strips, int total, int padded)
+{
+    const int wid = og_xcd_remap(blockIdx.x, padded);
+    if (wid >= total) return;
+    const int plane = wid / nbands, band = wid % nbands;
+    const TileGeom g = make_geom(H, W, rows, band, panel_strips, 4);
+    float acc = 0.f;
+    walk_panel<4, PF>(in + (size_t)plane * H * W, g, [&](int, const Px<4> &v, const Px<4> &m) {
+        acc += (v.c[0] == m.c[0]) + (v.c[1] == m.c[1]) + (v.c[2] == m.c[2]) + (v.c[3] == m.c[3]);
+    });
+    if (acc == -1.f) sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int PF>
+float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int k, int rows, void *ws, int iters, bool stream_only)
+{
+    const int strips = W / 4, nwaves = (strips + kInterior - 1) / kInterior, panel = (strips + nwaves - 1) / nwaves;
+    const int nbands = (H + rows - 1) / rows;
+    const long total = planes * nbands;
+    const int padded = (int)((total + 7) / 8 * 8);
+    uint64_t *keys = (uint64_t *)ws;
+    int *cnts = (int *)((char *)ws + og_align_up((size_t)planes * nbands * k * 8, 256));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e9, sum = 0;
+    for (int it = -2; it < iters; ++it) {
+        const float *in = bufs[(it + 2) % bufs.size()];
+        CK(hipEventRecord(a, 0));
+        if (stream_only)
+            hipLaunchKernelGGL((stream_only_kernel<PF>), dim3(padded), dim3(64 * nwaves), 0, 0, in, (float *)ws, H, W, rows, nbands, panel, (int)total, padded);
+        else
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8, 0, in, keys, cnts, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (it >= 0) { best = ms < best ? ms : best; sum += ms; }
+    }
+    return sum / iters * 1e3f;
+}
+
+int main(int argc, char **argv)
+{
+    const long planes = 136; const int H = 640, W = 640, k = 32;
+    const size_t n = (size_t)planes * H * W;
+    std::vector<float *> bufs(3);
+    for (int i = 0; i < 3; ++i) { CK(hipMalloc(&bufs[i], n * 4)); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, bufs[i], n, 17u * i + 1); }
+    void *ws; CK(hipMalloc(&ws, 64 << 20));
+    CK(hipDeviceSynchronize());
+    const double gb = n * 4 / 1e9;
+    printf("%-12s %5s %3s %9s %8s\n", "kernel", "rows", "pf", "us", "TB/s");
+    const int rows_list[] = {16, 32, 40, 64, 80, 128};
+    for (int so = 1; so >= 0; --so)
+        for (int rows : rows_list) {
+            float t2 = run_band<2>(bufs, planes, H, W, k, rows, ws, 20, so);
+            float t4 = run_band<4>(bufs, planes, H, W, k, rows, ws, 20, so);
+            float t8 = run_band<8>(bufs, planes, H, W, k, rows, ws, 20, so);
+            printf("%-12s %5d   2 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t2, gb / t2 * 1e3);
+            printf("%-12s %5d   4 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t4, gb / t4 * 1e3);
+            printf("%-12s %5d   8 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t8, gb / t8 * 1e3);
+        }
+    // full entry point (band + merge) at the library's default plan
+    float *os; int64_t *oi; CK(hipMalloc(&os, planes * k * 4)); CK(hipMalloc(&oi, planes * k * 8));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int it = 0; it < 5; ++it) {
+        CK(hipEventRecord(a, 0));
+        int rc = og_nms_topk_f32(bufs[it % 3], planes, H, W, k, os, oi, ws, 64 << 20, nullptr);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("og_nms_topk_f32 rc=%d %.1f us\n", rc, ms * 1e3);
+    }
+    return 0;
+}

@@ -53,6 +53,8 @@ def main():
     res['hmp_NMS (r+w)'] = (timeit(lambda i: decoder.hmp_NMS(hr[i % a.rotate]), a.iters), 2 * nbytes)
     res['joint_dets = NMS+topk (r)'] = (timeit(lambda i: decoder.joint_dets(hr[i % a.rotate], a.k), a.iters), nbytes)
     limbs = col.generate_limbs_lowres(hr[0], offs)
+    if os.environ.get('OG_DUMP_LIMBS'):
+        limbs.cpu().numpy().tofile(os.environ['OG_DUMP_LIMBS'])
     res['generate_limbs_lowres (K1+K2)'] = (timeit(lambda i: col.generate_limbs_lowres(hr[i % a.rotate], offs), a.iters), nbytes)
     res['group_device (K3)'] = (timeit(lambda i: grp.group_device(limbs), a.iters), 0)
     for k, ((med, mn), b) in res.items():
