@@ -92,7 +92,7 @@ def workspace(device, nbytes, tag="ws"):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=device)
+        buf = torch.zeros(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
 

@@ -24,6 +24,20 @@
 //   64-bit keys, ping-pong buffers) and raises its admission threshold, so the result is
 //   exact for any input.  Each band emits its k best keys; a second tiny kernel (one wave per
 //   plane) selects the plane's top-k from the band lists and writes scores/indices.
+//   Admission threshold (NMS mode).  Each workgroup also counts its candidates in a 256-bin LDS
+//   histogram (bins = exponent + 3 mantissa bits of the score, ds_add); after every PF rows one
+//   wave scans it with a DPP prefix sum and raises tau to the lower edge of the bin that holds
+//   the band's k-th best so far.  Across bands, a finished workgroup publishes the edge of its
+//   t-th best (t = k/4) into a per-plane slot table; a starting workgroup reads the table once
+//   and may start from the 4th largest published edge (4 bands x t >= k candidates lie above
+//   it).  Every bound is a true lower bound on the plane's k-th best whatever the timing, so no
+//   ordering protocol is needed and the top-k stays exact.  Measured lessons (MI355X):
+//     * with a perfect threshold the kernel streams at 4.9 TB/s (45 us for 223 MB), with none at
+//       3.9 TB/s: candidate handling, not HBM, is the gap;
+//     * ANY conditional vector-memory operation inside the streaming loop (histogram atomics,
+//       threshold loads) makes the compiler drain the prefetch queue (vmcnt(0)) every iteration,
+//       ~5 us each under load -- hence LDS-only refreshes and start/end-only global traffic;
+//     * rank-counting loops must read LDS wide (4 x ds_read_b128 per step, og_count_greater).
 #include <math.h>
 
 #include "og_common.h"
@@ -35,6 +49,16 @@ constexpr int kInterior = 62;     // interior lanes per wave panel
 constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
 constexpr uint32_t kLaneOob = 0x80000000u;  // offset of lanes outside the image
 constexpr uint32_t kRowOob = 0x40000000u;   // offset of rows the band must not read
+constexpr int kHistBins = 256;              // per-plane score histogram (NMS mode)
+constexpr int kHistShift = 20;              // bin = exponent (8 bits) + top 3 mantissa bits
+constexpr int kHistBase = (127 - 30) << 3;  // bin 0 starts at 2^-30 (everything smaller joins it)
+constexpr uint64_t kWsMagic = 0x4f47444543303031ull;  // workspace self-validation word
+
+__device__ __forceinline__ int hist_bin(int bits)
+{
+    return min(max((bits >> kHistShift) - kHistBase, 0), kHistBins - 1);
+}
+__device__ __forceinline__ int hist_edge_bits(int bin) { return bin == 0 ? 1 : (bin + kHistBase) << kHistShift; }
 
 template <int VEC>
 struct Px {
@@ -66,8 +90,13 @@ struct TileGeom {
 };
 
 // Walk rows r0..r1-1 of one panel; emit(row, centre values, 3x3 max incl. zero padding).
-template <int VEC, int PF, class Emit>
-__device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g, Emit &&emit)
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <int VEC, int PF, class Emit, class Begin = NoHook, class End = NoHook>
+__device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g, Emit &&emit, Begin &&iter_begin = NoHook(),
+                                           End &&iter_end = NoHook())
 {
     const int H = g.plane_rows, W = g.plane_cols;
     const uint32_t row_bytes = (uint32_t)W * 4u;
@@ -94,6 +123,7 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
 #pragma unroll
     for (int u = 0; u < PF; ++u) q[u] = load_row(g.r0 + 1 + u);
     for (int r = g.r0; r < g.r1; r += PF) {
+        iter_begin(r);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const Px<VEC> v_c = q[u];
@@ -109,6 +139,7 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
             hm_b = hm_c;
             v_b = v_c;
         }
+        iter_end(r);
     }
 }
 
@@ -169,6 +200,7 @@ struct WaveSeg {
     // strictly positive), plain mode compares floats
     int tau_bits;
     float tau_f;
+    int *hist;            // plane histogram (global) or nullptr
 
     __device__ __forceinline__ void set_tau(float t)
     {
@@ -182,8 +214,7 @@ struct WaveSeg {
         const int lane = threadIdx.x & 63;
         for (int i = lane; i < cnt; i += 64) {
             const uint64_t mine = cur[i];
-            int rank = 0;
-            for (int j = 0; j < cnt; ++j) rank += (cur[j] > mine);  // LDS broadcast reads
+            const int rank = og_count_greater(cur, cnt, mine);  // LDS broadcast reads
             if (rank < k) alt[rank] = mine;
         }
         __builtin_amdgcn_wave_barrier();
@@ -194,27 +225,40 @@ struct WaveSeg {
         }
     }
 
-    // `mask` = lanes whose candidate passes (it is the ballot of the compare)
-    __device__ __forceinline__ void push(uint64_t mask, float v, uint32_t idx, int k)
+    // pred = this lane's candidate passes, mask = its ballot (non-zero).  Kept lean: roughly
+    // every row carries a candidate on realistic maps, so this is not a cold path.
+    template <bool NMS_MODE>
+    __device__ __forceinline__ void push(bool pred, uint64_t mask, float v, uint32_t idx, int k)
     {
-        if (mask == 0) return;
         const int n = __builtin_popcountll(mask);
-        if (cnt + n > cap) compact(k);
+        if (__builtin_expect(cnt + n > cap, 0)) compact(k);
         const int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-        const int lane = threadIdx.x & 63;
-        if ((mask >> lane) & 1ull) cur[pos] = og_make_key(v, idx);
+        if (pred) {
+            // NMS mode only admits v > 0, whose order-preserving key is just the bit pattern with the top bit set
+            const uint64_t key = NMS_MODE ? (((uint64_t)(__builtin_bit_cast(uint32_t, v) | 0x80000000u) << 32) | (uint32_t)~idx)
+                                          : og_make_key(v, idx);
+            cur[pos] = key;
+            if (NMS_MODE && hist) atomicAdd(hist + hist_bin(__builtin_bit_cast(int, v)), 1);
+        }
         cnt += n;
     }
 };
 
-template <int VEC, bool NMS_MODE, int PF>
+// ABL (tuning harness only): 0 = product; 1 = compute the admission masks but never push
+template <int VEC, bool NMS_MODE, int PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * kMaxWaves)
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
+                 int *__restrict__ hist_all, const uint64_t *__restrict__ ws_magic, uint64_t magic,
                  int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded)
 {
-    extern __shared__ uint64_t smem[];
-    __shared__ int s_cnt[kMaxWaves];
-    __shared__ uint64_t *s_list[kMaxWaves];
+    // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
+    // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
+    extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+    int *s_hist = reinterpret_cast<int *>(smem + (size_t)(blockDim.x >> 6) * 2 * cap);
+    int *s_cnt = s_hist + kHistBins;
+    int *s_slot = s_cnt + kMaxWaves;   // which of the 2*nwaves key buffers holds wave w's final list
+    int *s_tau_p = s_slot + kMaxWaves;
+#define s_tau (*s_tau_p)
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
     const int plane = wid / nbands, band = wid % nbands;
@@ -229,41 +273,148 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     seg.cnt = 0;
     if (NMS_MODE) { seg.tau_bits = 1; seg.tau_f = 0.f; }  // bits >= 1  <=>  v > +0
     else seg.set_tau(-INFINITY);
+    if (ABL == 2) seg.set_tau(0.035f);  // harness: what a perfect plane-wide threshold would buy
+    // Plane-wide admission threshold without atomics.  Each workgroup counts its candidates in an
+    // LDS histogram (ds_add).  After every iteration (PF rows) one wave -- the duty rotates -- scans it and
+    //   * publishes E_t = lower edge of the bin holding the band's t-th best so far,
+    //     t = ceil(k / nbands), into the band's own slot of a per-plane table (plain sc1 store);
+    //   * reads all slots of the plane (one sc1 dword per lane): if every band has published,
+    //     min_b E_t(b) is a lower bound on the plane's k-th best (each band owns >= t candidates
+    //     above its own E_t, hence nbands*t >= k above the minimum);
+    //   * also takes the band's own k-th best edge;
+    // and hands max(those) to the other waves through LDS.  Slots only grow, so stale reads are
+    // merely weaker bounds: no ordering is needed and the top-k stays exact.  The table is trusted
+    // only if the workspace carries this geometry's magic word (zeroed + stamped by the merge
+    // kernel of the previous call).
+    int *gslot = (NMS_MODE && hist_all && *ws_magic == magic) ? hist_all + (size_t)plane * nbands : nullptr;
+    seg.hist = gslot ? s_hist : nullptr;
+    if (gslot) {
+        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+        if (threadIdx.x == 0) s_tau = 1;
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t srsrc =
+        __builtin_amdgcn_make_buffer_rsrc(gslot ? gslot : hist_all, 0, gslot ? nbands * 4 : 0, 0x00020000);
+    const int lane_id = threadIdx.x & 63;
+    const int t_band = (k + 3) / 4;  // any 4 finished bands give a bound
+    const int nwaves_ = blockDim.x >> 6;
+    int iter = 0, published = 0;
+    bool fetched = false;
+    if (gslot) {
+        // bound from the bands that already finished (earlier dispatch rounds): the `need` largest
+        // published E_t values cover need*t >= k candidates, so their minimum bounds the k-th best
+        const int sv = __builtin_amdgcn_raw_buffer_load_b32(srsrc, lane_id * 4, 0, 16);  // lanes >= nbands read 0
+        const int need = (k + t_band - 1) / t_band;
+        int rank = 0;  // number of slots strictly greater (ties by lane) than this lane's
+        for (int b = 0; b < nbands; ++b) {
+            const int o = __builtin_amdgcn_readlane(sv, b);
+            rank += (o > sv) || (o == sv && b < lane_id);
+        }
+        const uint64_t pick = __builtin_amdgcn_ballot_w64(lane_id < nbands && sv > 0 && rank == need - 1);
+        if (pick != 0ull) {
+            const int bound = __builtin_amdgcn_readlane(sv, __builtin_ctzll(pick));
+            if (bound > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, bound));
+            if (threadIdx.x == 0) atomicMax(&s_tau, bound);
+        }
+    }
+    auto iter_begin = [&](int) {
+        if (!NMS_MODE || !gslot) return;
+        const int t = s_tau;  // LDS broadcast
+        if (t > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, t));
+        fetched = (iter % nwaves_) == wave;  // the refresh duty rotates over the waves: one per iteration
+        ++iter;
+    };
+    auto iter_end = [&](int) {
+        if (!NMS_MODE || !gslot) return;
+        // no global memory traffic in here: any extra (conditional) vector-memory operation in the
+        // streaming loop makes the compiler drain the row prefetch queue (vmcnt(0)) every iteration,
+        // which under a saturated memory system costs ~5 us each.  The slot table is read once when
+        // the workgroup starts and written once when it ends; this refresh only scans LDS.
+        if (!fetched) return;
+        // lane l holds local bins 4l..4l+3; inclusive prefix over lanes by DPP, then suffix sums
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i h = *reinterpret_cast<const v4i *>(s_hist + 4 * lane_id);
+        const int mine = h.x + h.y + h.z + h.w;
+        int pre = mine;
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false);  // row_shr:1
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);  // row_shr:2
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);  // row_shr:4
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);  // row_shr:8
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+        pre += __builtin_amdgcn_update_dpp(0, pre, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+        const int total = __builtin_amdgcn_readlane(pre, 63);
+        const int suf = total - pre + mine;   // candidates in bins >= 4l
+        const int above = suf - mine;
+        auto edge_of = [&](int want) {        // lower edge (as float bits) of the bin holding the want-th best
+            const uint64_t ge = __builtin_amdgcn_ballot_w64(suf >= want);
+            if (ge == 0ull) return 0;
+            const int top = 63 - __builtin_clzll(ge);
+            int bin = 4 * lane_id;
+            if (above + h.w >= want) bin += 3;
+            else if (above + h.w + h.z >= want) bin += 2;
+            else if (above + h.w + h.z + h.y >= want) bin += 1;
+            return __builtin_amdgcn_readlane(hist_edge_bits(bin), top);
+        };
+        const int e_k = edge_of(k), e_t = edge_of(t_band);
+        if (e_t > published) published = e_t;  // stored by the next iteration's unconditional store
+        const int edge = e_k;
+        if (edge > seg.tau_bits) {
+            seg.set_tau(__builtin_bit_cast(float, edge));
+            if (lane_id == 0) atomicMax(&s_tau, edge);
+        }
+    };
 
     walk_panel<VEC, PF>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
+        bool pj[VEC];
         uint64_t mk[VEC];
         uint64_t any = 0;
+        const bool emits = g.interior;  // (VEC == 1: every interior lane is inside the image as well)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            bool p;
-            const bool emits = g.interior && (VEC == 4 || g.col + j < W);
             if (NMS_MODE) {
                 const int lane_tau = emits ? seg.tau_bits : 0x7fffffff;
-                p = (__builtin_bit_cast(int, v.c[j]) >= lane_tau) && (v.c[j] == m.c[j]);
+                pj[j] = (__builtin_bit_cast(int, v.c[j]) >= lane_tau) && (v.c[j] == m.c[j]);
             } else {
                 const float lane_tau = emits ? seg.tau_f : INFINITY;
-                p = v.c[j] >= lane_tau;
+                pj[j] = v.c[j] >= lane_tau;
             }
-            mk[j] = __builtin_amdgcn_ballot_w64(p);
+            mk[j] = __builtin_amdgcn_ballot_w64(pj[j]);
             any |= mk[j];
         }
-        if (__builtin_expect(any != 0ull, 0)) {
+        if (ABL == 1) {
+            seg.cnt += (int)(any >> 63);  // keep the masks alive
+            return;
+        }
+        if (any != 0ull) {
             const uint32_t base = (uint32_t)row * (uint32_t)W + (uint32_t)g.col;
+            const int tau_in = seg.tau_bits;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
+                if (mk[j] == 0ull) continue;
+                bool p = pj[j];
                 uint64_t mj = mk[j];
-                if (j > 0) {  // an earlier component may have raised tau: re-test
-                    const bool p = NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.tau_bits) : (v.c[j] >= seg.tau_f);
-                    mj &= __builtin_amdgcn_ballot_w64(p);
+                if (seg.tau_bits != tau_in) {  // an earlier component's compaction raised tau: re-test
+                    p = p && (NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.tau_bits) : (v.c[j] >= seg.tau_f));
+                    mj = __builtin_amdgcn_ballot_w64(p);
+                    if (mj == 0ull) continue;
                 }
-                seg.push(mj, v.c[j], base + j, k);
+                seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
             }
         }
-    });
+    }, iter_begin, iter_end);
 
+    if (NMS_MODE && gslot) {  // publish this band's t-th best (all its candidates are counted by now)
+        __syncthreads();
+        if (wave == 0) {
+            fetched = true;
+            iter_end(0);
+            if (lane_id == 0 && published > 0)
+                __hip_atomic_store(gslot + band, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
-    if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_list[wave] = seg.cur; }
+    if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_slot[wave] = (int)((seg.cur - smem) / cap); }
     __syncthreads();
     int total_keys = 0;
     for (int w = 0; w < nwaves; ++w) total_keys += s_cnt[w];
@@ -271,16 +422,13 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     for (int t = threadIdx.x; t < total_keys; t += blockDim.x) {
         int w = 0, o = t;
         while (o >= s_cnt[w]) { o -= s_cnt[w]; ++w; }
-        const uint64_t key = s_list[w][o];
+        const uint64_t key = smem[(size_t)s_slot[w] * cap + o];
         int rank = 0;
-        for (int w2 = 0; w2 < nwaves; ++w2) {
-            const uint64_t *kk = s_list[w2];
-            const int c2 = s_cnt[w2];
-            for (int j = 0; j < c2; ++j) rank += (kk[j] > key);
-        }
+        for (int w2 = 0; w2 < nwaves; ++w2) rank += og_count_greater(smem + (size_t)s_slot[w2] * cap, s_cnt[w2], key);
         if (rank < k) out[rank] = key;
     }
     if (threadIdx.x == 0) band_cnt[(size_t)plane * nbands + band] = min(total_keys, k);
+#undef s_tau
 }
 
 // ---------------------------------------------------------------------------------------
@@ -293,10 +441,11 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 template <bool NMS_MODE>
 __global__ void __launch_bounds__(64)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
+                   int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
                    const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
                    float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
 {
-    extern __shared__ uint64_t lds64[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const int plane = blockIdx.x, lane = threadIdx.x;
     const int n_all = nbands * k;
     uint64_t *all = lds64;             // n_all keys (0 = empty slot)
@@ -308,6 +457,9 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
     float *os = out_scores + (size_t)plane * k;
     int64_t *oi = out_inds + (size_t)plane * k;
 
+    if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
+        for (int i = lane; i < nbands; i += 64) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
+    if (blockIdx.x == 0 && lane == 0) *ws_magic = hist_all ? magic : 0ull;
     for (int b = lane; b < nbands; b += 64) s_cnts[b] = gc[b];
     if (lane == 0) s_bound = 0ull;
     __syncthreads();
@@ -315,12 +467,12 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
     __syncthreads();
     // A) k-th largest of the subset {first t_sub keys of each band}
     const int n_sub = nbands * t_sub;
+    uint64_t *subk = flt;  // the filtered list is built later: reuse its space
+    for (int i = lane; i < n_sub; i += 64) subk[i] = all[(i / t_sub) * k + i % t_sub];
+    __syncthreads();
     for (int i = lane; i < n_sub; i += 64) {
-        const uint64_t mine = all[(i / t_sub) * k + i % t_sub];
-        if (mine == 0ull) continue;
-        int rank = 0;
-        for (int j = 0; j < n_sub; ++j) rank += (all[(j / t_sub) * k + j % t_sub] > mine);
-        if (rank == k - 1) s_bound = mine;
+        const uint64_t mine = subk[i];
+        if (mine != 0ull && og_count_greater(subk, n_sub, mine) == k - 1) s_bound = mine;
     }
     __syncthreads();
     const uint64_t bound = s_bound;
@@ -338,8 +490,7 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
     // C) rank and emit
     for (int i = lane; i < nf; i += 64) {
         const uint64_t mine = flt[i];
-        int rank = 0;
-        for (int j = 0; j < nf; ++j) rank += (flt[j] > mine);
+        const int rank = og_count_greater(flt, nf, mine);
         if (rank < k) {
             os[rank] = og_key_value(mine);
             oi[rank] = (int64_t)og_key_index(mine);
@@ -378,7 +529,8 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
 
 struct Plan {
     int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;
-    size_t keys_off, cnt_off, bytes;
+    size_t keys_off, cnt_off, hist_off, magic_off, bytes;
+    uint64_t magic;
 };
 
 int env_int(const char *name, int dflt)
@@ -394,7 +546,7 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     p->nwaves = (strips + kInterior - 1) / kInterior;
     if (p->nwaves > kMaxWaves) return false;
     p->panel_strips = (strips + p->nwaves - 1) / p->nwaves;
-    int rows = env_int("OG_NMS_ROWS", 40);
+    int rows = env_int("OG_NMS_ROWS", 80);
     rows = max(rows, (H + 255) / 256);  // the merge kernel indexes at most 256 bands
     rows = min(rows, H);
     p->rows = rows;
@@ -403,9 +555,16 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     if ((size_t)p->nwaves * 2 * p->cap * sizeof(uint64_t) > 60 * 1024) return false;
     // subset depth for the merge's lower bound: nbands * t_sub >= k whenever possible
     p->t_sub = min(k, max(2, (k + p->nbands - 1) / p->nbands + 1));
-    p->keys_off = 0;
-    p->cnt_off = og_align_up((size_t)planes * p->nbands * k * sizeof(uint64_t), 256);
+    // [magic | histograms | band keys | band counts]; the magic word sits at offset 0 for every
+    // shape and encodes the shape, so a call with another geometry (or in plain top-k mode)
+    // invalidates whatever histogram state an earlier geometry left behind
+    p->magic_off = 0;
+    p->hist_off = 256;
+    p->keys_off = p->hist_off + og_align_up((size_t)planes * kHistBins * sizeof(int), 256);
+    p->cnt_off = p->keys_off + og_align_up((size_t)planes * p->nbands * k * sizeof(uint64_t), 256);
     p->bytes = p->cnt_off + og_align_up((size_t)planes * p->nbands * sizeof(int), 256);
+    p->magic = kWsMagic ^ ((uint64_t)planes * 0x9E3779B97F4A7C15ull + (uint64_t)H * 0x100000001B3ull +
+                           (uint64_t)W * 0xC2B2AE3D27D4EB4Full + (uint64_t)k * 0x165667B19E3779F9ull);
     return true;
 }
 
@@ -425,23 +584,25 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
     uint64_t *keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
     int *cnts = reinterpret_cast<int *>((char *)workspace + p.cnt_off);
+    int *hist = (NMS_MODE && p.nbands <= 64) ? reinterpret_cast<int *>((char *)workspace + p.hist_off) : nullptr;
+    uint64_t *magic = reinterpret_cast<uint64_t *>((char *)workspace + p.magic_off);
 
     const long total = planes * p.nbands;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
     const dim3 block(64 * p.nwaves);
-    const size_t lds = (size_t)p.nwaves * 2 * p.cap * sizeof(uint64_t);
+    const size_t lds = (size_t)p.nwaves * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
     if (p.vec == 4)
-        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts, H,
-                           W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
     else
-        hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts, H,
-                           W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
+        hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
-    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(64), mlds, stream, keys, cnts, in, H,
-                       W, k, p.nbands, p.t_sub, out_scores, out_inds);
+    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(64), mlds, stream, keys, cnts, hist,
+                       magic, p.magic, in, H, W, k, p.nbands, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -107,6 +107,24 @@ def test_joint_dets_degenerate_planes(dev):
     assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
 
 
+def test_joint_dets_histogram_state_reuse(dev):
+    """K1 keeps a per-plane score histogram in its workspace between calls (self-validated by a
+    shape-encoding magic word): repeated calls, changing shapes and plain top-k calls in between must
+    all stay exact."""
+    seq = [((1, 3, 96, 128), 31), ((1, 3, 96, 128), 32), ((2, 2, 64, 64), 33), ((1, 3, 96, 128), 34),
+           ((1, 3, 96, 128), 35)]
+    for shape, seed in seq:
+        hm = oracle.bicubic4(synth.synth_batch(seed, shape[0], shape[2], shape[3], n_persons=3)[0][:, :shape[1]])
+        s, i, _, _ = decoder.joint_dets(torch.from_numpy(hm).to(dev), 32)
+        rs, ri, _, _ = oracle.nms_topk(hm, 32)
+        assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+        if seed == 33:  # plain top-k shares the workspace and must invalidate the histogram state
+            z = synth.noise_batch(5, (1, 3, 96, 128))
+            s2, i2, _, _ = decoder.topK_channel(torch.from_numpy(z).to(dev), K=32)
+            r2 = oracle.topk(z, 32)
+            assert (s2.cpu().numpy() == r2[0]).all() and (i2.cpu().numpy() == r2[1]).all()
+
+
 def test_topk_errors(dev):
     z = torch.zeros(1, 1, 4, 5, device=dev)
     with pytest.raises(RuntimeError):

@@ -37,7 +37,7 @@ stream_only_kernel(const float *__restrict__ in, float *__restrict__ sink, int H
 }
 
 template <int PF>
-float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int k, int rows, void *ws, int iters, bool stream_only)
+float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int k, int rows, void *ws, int iters, int mode)
 {
     const int strips = W / 4, nwaves = (strips + kInterior - 1) / kInterior, panel = (strips + nwaves - 1) / nwaves;
     const int nbands = (H + rows - 1) / rows;
@@ -51,10 +51,14 @@ float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int 
     for (int it = -2; it < iters; ++it) {
         const float *in = bufs[(it + 2) % bufs.size()];
         CK(hipEventRecord(a, 0));
-        if (stream_only)
+        if (mode == 1)
             hipLaunchKernelGGL((stream_only_kernel<PF>), dim3(padded), dim3(64 * nwaves), 0, 0, in, (float *)ws, H, W, rows, nbands, panel, (int)total, padded);
+        else if (mode == 3)
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 2>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+        else if (mode == 2)
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 1>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
         else
-            hipLaunchKernelGGL((band_topk_kernel<4, true, PF>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8, 0, in, keys, cnts, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -71,17 +75,22 @@ int main(int argc, char **argv)
     for (int i = 0; i < 3; ++i) { CK(hipMalloc(&bufs[i], n * 4)); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, bufs[i], n, 17u * i + 1); }
     void *ws; CK(hipMalloc(&ws, 64 << 20));
     CK(hipDeviceSynchronize());
+    if (argc > 1) {  // realistic hi-res heatmaps dumped by tools/kbench.py (OG_DUMP_HR)
+        std::vector<float> h(n);
+        FILE *f = fopen(argv[1], "rb");
+        if (!f || fread(h.data(), 4, n, f) != n) { printf("cannot read %s\n", argv[1]); return 1; }
+        fclose(f);
+        for (int i = 0; i < 3; ++i) CK(hipMemcpy(bufs[i], h.data(), n * 4, hipMemcpyHostToDevice));
+        printf("input: %s\n", argv[1]);
+    }
     const double gb = n * 4 / 1e9;
     printf("%-12s %5s %3s %9s %8s\n", "kernel", "rows", "pf", "us", "TB/s");
-    const int rows_list[] = {16, 32, 40, 64, 80, 128};
-    for (int so = 1; so >= 0; --so)
+    const char *names[] = {"band_topk", "stream_only", "masks_only", "ideal_tau"};
+    const int rows_list[] = {32, 40, 80};
+    for (int mode : {1, 2, 3, 0})
         for (int rows : rows_list) {
-            float t2 = run_band<2>(bufs, planes, H, W, k, rows, ws, 20, so);
-            float t4 = run_band<4>(bufs, planes, H, W, k, rows, ws, 20, so);
-            float t8 = run_band<8>(bufs, planes, H, W, k, rows, ws, 20, so);
-            printf("%-12s %5d   2 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t2, gb / t2 * 1e3);
-            printf("%-12s %5d   4 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t4, gb / t4 * 1e3);
-            printf("%-12s %5d   8 %9.1f %8.2f\n", so ? "stream_only" : "band_topk", rows, t8, gb / t8 * 1e3);
+            float t4 = run_band<4>(bufs, planes, H, W, k, rows, ws, 20, mode);
+            printf("%-12s %5d   4 %9.1f %8.2f\n", names[mode], rows, t4, gb / t4 * 1e3);
         }
     // full entry point (band + merge) at the library's default plan
     float *os; int64_t *oi; CK(hipMalloc(&os, planes * k * 4)); CK(hipMalloc(&oi, planes * k * 8));

@@ -43,6 +43,8 @@ def main():
     offs = torch.from_numpy(off).to(dev)
     hr = [upsample4(x, 'bicubic') for x in lr]
     n, c, H, W = hr[0].shape
+    if os.environ.get('OG_DUMP_HR'):
+        hr[0].cpu().numpy().tofile(os.environ['OG_DUMP_HR'])
     nbytes = n * c * H * W * 4
     from offsetguided_amd.decoder.collect import LimbsCollect
     from offsetguided_amd.decoder.group import GreedyGroup
