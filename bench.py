@@ -75,16 +75,12 @@ def bench_init(model, seed):
 
 def main():
     a = parse()
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    from offsetguided_amd import sharding
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
+    rank, local_rank, world = sharding.env_rank()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    sharding.init(backend='nccl', device=dev)   # one process per GPU; RCCL only for barrier + timing MAX
 
     from offsetguided_amd import _lib, decoder, models, synth
     from offsetguided_amd.config import coco_data as cd
@@ -120,10 +116,7 @@ def main():
         return [([None, hm], [[], []], [[], []]), ([None, off], [[], []], [[], []])]
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
+        sharding.barrier(dev)
 
     def run_steps(n, first=0):
         pending, out = None, None
@@ -144,11 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stage_us = _lib.profile_stop()
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)
 
     # ---- decoder-only and backbone-only timings (outside the headline region) ----
     def timed(fn, n):
