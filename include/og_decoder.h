@@ -111,6 +111,19 @@ int og_flip_merge_f32(const float *hm, const float *off, int N, int C, int L, in
                       const int32_t *kp_perm, const int32_t *limb_perm, const int32_t *reserve_mask,
                       float *hm_out, float *off_out, void *stream);
 
+/* ---- backbone epilogues (bf16, channels-last / NHWC activations of the inference engine) ----
+ * The convolutions stay on MIOpen; these fuse what PyTorch would launch as separate elementwise
+ * kernels after each of them.
+ *
+ * og_bias_act_bf16: x (pixels, channels) bf16, in place:  x = act(x + bias[c] (+ skip))
+ *   = convolution.forward models/hourglass_104.py:26-30 (BN folded into bias, ReLU) and
+ *     residual.forward :70-79 (bn2 + skip, ReLU).  bias fp32[channels]; skip bf16 like x or NULL;
+ *     channels % 8 == 0; fp32 arithmetic, one rounding to bf16.
+ * og_upsample2_add_bf16: up (n,H,W,channels) += nearest_x2(low (n,H/2,W/2,channels))
+ *   = kp_module.forward :183-190 (up1 + up2 merge). */
+int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream);
+int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@ SIGNATURES = {
     "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "og_bias_act_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "og_upsample2_add_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,110 @@
+// Backbone epilogues for the bf16 channels-last (NHWC) inference engine.
+//
+// MIOpen runs the convolutions (MFMA igemm); PyTorch would then launch separate elementwise
+// kernels for the (BN-folded) bias add, the residual add and the ReLU -- ~390 launches and two
+// to three full passes over every activation per forward.  These kernels do the whole epilogue of
+//   convolution.forward  (models/hourglass_104.py:26-30):  relu(conv + b)
+//   residual.forward     (models/hourglass_104.py:70-79):  relu(conv2 + b2 + skip)
+//   kp_module.forward    (models/hourglass_104.py:183-190): up1 + nearest_x2(low3)
+// in one in-place pass, 16 B (8 x bf16) per lane, fp32 arithmetic, one rounding to bf16.
+#include "og_common.h"
+
+namespace {
+
+typedef unsigned short v8u16 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    // round-to-nearest-even on the bit pattern; activations here are finite
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <bool SKIP, bool RELU>
+__global__ void __launch_bounds__(256)
+bias_act_kernel(unsigned short *__restrict__ x, const float *__restrict__ bias, const unsigned short *__restrict__ skip,
+                long groups, int cgroups)
+{
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(g % cgroups) * 8;
+        v8u16 v = *reinterpret_cast<const v8u16 *>(x + g * 8);
+        v8u16 s;
+        if (SKIP) s = *reinterpret_cast<const v8u16 *>(skip + g * 8);
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + c0), b1 = *reinterpret_cast<const float4 *>(bias + c0 + 4);
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf2f(v[j]) + b[j];
+            if (SKIP) f += bf2f(s[j]);
+            if (RELU) f = fmaxf(f, 0.f);
+            v[j] = f2bf(f);
+        }
+        *reinterpret_cast<v8u16 *>(x + g * 8) = v;
+    }
+}
+
+// up[n][y][x][c] += low[n][y/2][x/2][c]   (nearest x2 upsample fused into the merge add)
+__global__ void __launch_bounds__(256)
+upsample2_add_kernel(unsigned short *__restrict__ up, const unsigned short *__restrict__ low, long groups, int cgroups,
+                     int H, int W)
+{
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(g % cgroups);
+        long p = g / cgroups;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        const long n = p / H;
+        const long src = ((n * (H / 2) + y / 2) * (W / 2) + x / 2) * cgroups + cg;
+        v8u16 v = *reinterpret_cast<const v8u16 *>(up + g * 8);
+        const v8u16 l = *reinterpret_cast<const v8u16 *>(low + src * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(l[j]));
+        *reinterpret_cast<v8u16 *>(up + g * 8) = v;
+    }
+}
+
+unsigned grid_for(long groups)
+{
+    const long blocks = (groups + 255) / 256;
+    return (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);  // <= 8 blocks per CU, grid-stride beyond
+}
+
+}  // namespace
+
+OG_API int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream)
+{
+    const char *name = "og_bias_act_bf16";
+    OG_REQUIRE(x && bias, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(pixels > 0 && channels > 0 && channels % 8 == 0, OG_EINVAL, "%s: channels must be a multiple of 8", name);
+    OG_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)bias % 16 == 0 && (uintptr_t)skip % 16 == 0, OG_EINVAL,
+               "%s: pointers must be 16-byte aligned", name);
+    const int cg = channels / 8;
+    const long groups = pixels * cg;
+    unsigned short *xp = (unsigned short *)x;
+    const unsigned short *sp = (const unsigned short *)skip;
+    const dim3 grid(grid_for(groups)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (skip && relu) hipLaunchKernelGGL((bias_act_kernel<true, true>), grid, block, 0, st, xp, bias, sp, groups, cg);
+    else if (skip) hipLaunchKernelGGL((bias_act_kernel<true, false>), grid, block, 0, st, xp, bias, sp, groups, cg);
+    else if (relu) hipLaunchKernelGGL((bias_act_kernel<false, true>), grid, block, 0, st, xp, bias, sp, groups, cg);
+    else hipLaunchKernelGGL((bias_act_kernel<false, false>), grid, block, 0, st, xp, bias, sp, groups, cg);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream)
+{
+    const char *name = "og_upsample2_add_bf16";
+    OG_REQUIRE(up && low, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(n > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && channels % 8 == 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE((uintptr_t)up % 16 == 0 && (uintptr_t)low % 16 == 0, OG_EINVAL, "%s: pointers must be 16-byte aligned", name);
+    const int cg = channels / 8;
+    const long groups = n * H * W * cg;
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3(grid_for(groups)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned short *)up, (const unsigned short *)low, groups, cg, H, W);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

@@ -3,6 +3,9 @@
 The dense convolutions stay on PyTorch-ROCm (MIOpen -> MFMA); what this file adds is the shape
 the hardware wants:
   * every BatchNorm folded into the preceding convolution (160 BN layers disappear);
+  * bias + ReLU + residual add after each convolution, and nearest-x2-upsample + add at every
+    hourglass merge, run as ONE hand-written HIP pass each (csrc/epilogue.hip) instead of 2-3
+    PyTorch elementwise launches;
   * bf16 activations/weights in channels-last (NHWC) layout, fp32 accumulation inside MIOpen;
   * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only);
   * the whole forward (~500 launches, tiny 5x5..20x20 tiles deep in the hourglass) is captured
@@ -14,6 +17,7 @@ The result keeps the reference nesting [ (hmps[S], bg[S], jo[S]), (offs[S], spre
 import torch
 import torch.nn.functional as F
 
+from .. import _lib
 from .hourglass_104 import ConvBlock, HourglassLevel, Residual
 
 
@@ -28,34 +32,58 @@ def _fold(conv, bn):
     return w, b
 
 
-class _Conv:
-    __slots__ = ('w', 'b', 'stride', 'pad', 'relu')
+def _epilogue(y, bias32, bias_lp, skip, relu, fused):
+    """y = act(y + bias (+ skip)) in place.  fused: one hand-written HIP pass (og_bias_act_bf16);
+    otherwise plain torch ops (CPU / fp32 checking path)."""
+    if fused:
+        n, c, h, w = y.shape
+        assert y.is_contiguous(memory_format=torch.channels_last) and (skip is None or skip.shape == y.shape)
+        if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+        lib = _lib.load()
+        _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias32), _lib.ptr(skip) if skip is not None else None,
+                                        n * h * w, c, int(relu), _lib.stream_ptr(y.device)), lib)
+        return y
+    y += bias_lp.view(1, -1, 1, 1)
+    if skip is not None:
+        y += skip
+    return F.relu_(y) if relu else y
 
-    def __init__(self, conv, bn, relu, dtype):
+
+class _Conv:
+    """Folded conv: weight in the engine dtype (channels-last), bias kept apart for the epilogue."""
+
+    def __init__(self, conv, bn, relu, dtype, fused):
         w, b = _fold(conv, bn)
         self.w = w.to(dtype).contiguous(memory_format=torch.channels_last)
+        self.b32 = b.float().contiguous()
         self.b = b.to(dtype)
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
+        self.fused = fused and w.shape[0] % 8 == 0
 
-    def __call__(self, x):
-        y = F.conv2d(x, self.w, self.b, self.stride, self.pad)
-        return F.relu_(y) if self.relu else y
+    def raw(self, x):
+        return F.conv2d(x, self.w, None, self.stride, self.pad)
+
+    def __call__(self, x, skip=None):
+        return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
 
 
 class _Residual:
-    def __init__(self, m, dtype):
-        self.c1 = _Conv(m.conv1, m.bn1, True, dtype)
-        self.c2 = _Conv(m.conv2, m.bn2, False, dtype)
-        self.skip = _Conv(m.skip[0], m.skip[1], False, dtype) if len(m.skip) else None
+    def __init__(self, m, dtype, fused):
+        self.c1 = _Conv(m.conv1, m.bn1, True, dtype, fused)
+        self.c2 = _Conv(m.conv2, m.bn2, True, dtype, fused)       # ReLU after the residual sum
+        self.skip = _Conv(m.skip[0], m.skip[1], False, dtype, fused) if len(m.skip) else None
+        if self.skip is not None:  # the projection's bias rides on conv2's epilogue
+            self.c2.b32 = (self.c2.b32 + self.skip.b32).contiguous()
+            self.c2.b = self.c2.b32.to(dtype)
 
     def __call__(self, x):
-        y = self.c2(self.c1(x))
-        y += x if self.skip is None else self.skip(x)
-        return F.relu_(y)
+        shortcut = x if self.skip is None else self.skip.raw(x)
+        return self.c2(self.c1(x), skip=shortcut)
 
 
-def _seq(mods, dtype):
-    return [_Residual(m, dtype) for m in mods]
+def _seq(mods, dtype, fused):
+    return [_Residual(m, dtype, fused) for m in mods]
 
 
 def _run(seq, x):
@@ -65,16 +93,22 @@ def _run(seq, x):
 
 
 class _Level:
-    def __init__(self, m, dtype):
-        self.up1, self.low1, self.low3 = _seq(m.up1, dtype), _seq(m.low1, dtype), _seq(m.low3, dtype)
-        self.low2 = _Level(m.low2, dtype) if isinstance(m.low2, HourglassLevel) else _seq(m.low2, dtype)
+    def __init__(self, m, dtype, fused):
+        self.fused = fused
+        self.up1, self.low1, self.low3 = _seq(m.up1, dtype, fused), _seq(m.low1, dtype, fused), _seq(m.low3, dtype, fused)
+        self.low2 = _Level(m.low2, dtype, fused) if isinstance(m.low2, HourglassLevel) else _seq(m.low2, dtype, fused)
 
     def __call__(self, x):
         low = _run(self.low1, x)
         low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
         low = _run(self.low3, low)
         up = _run(self.up1, x)
-        up += F.interpolate(low, scale_factor=2, mode='nearest')
+        if self.fused:  # up += nearest_x2(low) in one pass
+            n, c, h, w = up.shape
+            lib = _lib.load()
+            _lib.check(lib.og_upsample2_add_bf16(_lib.ptr(up), _lib.ptr(low), n, h, w, c, _lib.stream_ptr(up.device)), lib)
+        else:
+            up += F.interpolate(low, scale_factor=2, mode='nearest')
         return up
 
 
@@ -95,15 +129,20 @@ class InferenceEngine:
         dev_model = model.to(self.device).eval()
         net = dev_model.basenet
         assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
-        self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype), _Residual(net.pre[1], dtype)]
-        self.kps = [_Level(net.kps[s], dtype) for s in range(self.stage + 1)]
-        self.cnvs = [_Conv(net.cnvs[s].conv, net.cnvs[s].bn, True, dtype) for s in range(self.stage + 1)]
-        self.inters = [_Residual(net.inters[s], dtype) for s in range(self.stage)]
-        self.inters_ = [_Conv(net.inters_[s][0], net.inters_[s][1], False, dtype) for s in range(self.stage)]
-        self.cnvs_ = [_Conv(net.cnvs_[s][0], net.cnvs_[s][1], False, dtype) for s in range(self.stage)]
+        # hand-written HIP epilogues (bias/ReLU/residual add, upsample+add) on the GPU bf16 path
+        fused = self.fused = (self.device.type == 'cuda' and dtype == torch.bfloat16)
+        self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype, fused), _Residual(net.pre[1], dtype, fused)]
+        self.kps = [_Level(net.kps[s], dtype, fused) for s in range(self.stage + 1)]
+        self.cnvs = [_Conv(net.cnvs[s].conv, net.cnvs[s].bn, True, dtype, fused) for s in range(self.stage + 1)]
+        self.inters = [_Residual(net.inters[s], dtype, fused) for s in range(self.stage)]
+        self.inters_ = [_Conv(net.inters_[s][0], net.inters_[s][1], True, dtype, fused) for s in range(self.stage)]
+        self.cnvs_ = [_Conv(net.cnvs_[s][0], net.cnvs_[s][1], False, dtype, fused) for s in range(self.stage)]
+        for a_, b_ in zip(self.inters_, self.cnvs_):  # relu(inters_(inter) + cnvs_(feat)): one epilogue, summed biases
+            a_.b32 = (a_.b32 + b_.b32).contiguous()
+            a_.b = a_.b32.to(dtype)
         hm_head, off_head = dev_model.headnets[0], dev_model.headnets[1]
-        self.hm = _Conv(hm_head.hp_convs[self.stage], None, False, dtype)
-        self.off = _Conv(off_head.reg_convs[self.stage], None, False, dtype)
+        self.hm = _Conv(hm_head.hp_convs[self.stage], None, False, dtype, False)
+        self.off = _Conv(off_head.reg_convs[self.stage], None, False, dtype, False)
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -117,14 +156,14 @@ class InferenceEngine:
         for s in range(self.stage + 1):
             feat = self.cnvs[s](self.kps[s](inter))
             if s < self.stage:
-                mix = self.inters_[s](inter)
-                mix += self.cnvs_[s](feat)
-                inter = self.inters[s](F.relu_(mix))
+                inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
         hm = self.hm(feat).float().contiguous(memory_format=torch.contiguous_format)
         off = self.off(feat).float().contiguous(memory_format=torch.contiguous_format)
         return hm, off
 
     def _capture(self):
+        # MIOpen "find" picks per-shape kernels during the warm-up passes (1.4x over the defaults here)
+        torch.backends.cudnn.benchmark = True
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), torch.no_grad():

@@ -1,0 +1,69 @@
+"""Backbone side on the GPU: fused epilogue kernels vs torch ops, and the bf16 HIP-graph engine vs the
+eager fp32 module (tolerance-based: bf16 activations through ~100 layers)."""
+import argparse
+
+import pytest
+import torch
+
+from offsetguided_amd import _lib, models
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    return torch.device("cuda:0")
+
+
+def _nhwc(*shape, dev):
+    return torch.randn(*shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_bias_act_matches_torch(dev, relu, with_skip):
+    lib = _lib.load()
+    x = _nhwc(2, 256, 20, 12, dev=dev)
+    skip = _nhwc(2, 256, 20, 12, dev=dev) if with_skip else None
+    bias = torch.randn(256, device=dev)
+    ref = x.float() + bias.view(1, -1, 1, 1) + (skip.float() if with_skip else 0)
+    ref = (torch.relu(ref) if relu else ref).to(torch.bfloat16)              # single rounding, like the kernel
+    y = x.clone(memory_format=torch.preserve_format)
+    _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(skip) if with_skip else None,
+                                    2 * 20 * 12, 256, relu, _lib.stream_ptr(dev)), lib)
+    assert torch.equal(y, ref)
+
+
+def test_upsample2_add_matches_torch(dev):
+    lib = _lib.load()
+    up, low = _nhwc(2, 384, 10, 20, dev=dev), _nhwc(2, 384, 5, 10, dev=dev)
+    ref = (up.float() + torch.nn.functional.interpolate(low.float(), scale_factor=2, mode='nearest')).to(torch.bfloat16)
+    _lib.check(lib.og_upsample2_add_bf16(_lib.ptr(up), _lib.ptr(low), 2, 10, 20, 384, _lib.stream_ptr(dev)), lib)
+    assert torch.equal(up, ref)
+
+
+def test_engine_matches_eager_fp32(dev):
+    import bench
+    p = argparse.ArgumentParser()
+    models.net_cli(p)
+    model, _ = models.model_factory(p.parse_args(['--no-pretrain']))
+    bench.bench_init(model, 7)
+    for head in model.headnets:                      # undo bench_init's head shrink: compare real magnitudes
+        for m in head.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.data.mul_(1e4)
+    x = torch.randn(2, 3, 128, 128, device=dev)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        ref = model(x)
+    for use_graph in (False, True):
+        eng = models.InferenceEngine(model, 2, 128, 128, device=dev, use_graph=use_graph)
+        out = eng(x)
+        for h in (0, 1):
+            r, o = ref[h][0][-1].float(), out[h][0][-1]
+            assert o.dtype == torch.float32 and o.is_contiguous() and o.shape == r.shape
+            err = (o - r).abs().max().item() / r.abs().max().item()
+            assert err < 0.05, f"head {h}: relative error {err}"
+        assert out[0][0][0] is None and out[0][1] == [[], []]     # reference nesting, unused stack skipped
