@@ -44,24 +44,29 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
                      const int32_t *__restrict__ jf, const int32_t *__restrict__ jt, int L, int K,
                      float thre, float min_len, float resize, float *__restrict__ limbs)
 {
-    extern __shared__ float sm[];
-    float *tx = sm, *ty = sm + K, *ts = sm + 2 * K;
-    int *ti = reinterpret_cast<int *>(sm + 3 * K);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Kp = (K + 3) & ~3;                 // to-candidate coordinates interleaved (x,y), padded to 4
+    float2 *txy = reinterpret_cast<float2 *>(sm);
+    float *ts = sm + 2 * Kp;
+    int *ti = reinterpret_cast<int *>(sm + 3 * Kp);
     const int n = blockIdx.x / L, l = blockIdx.x % L, lane = threadIdx.x;
     const int cf = jf[l], ct = jt[l];
     const long HW = (long)H * W;
     const float *sf = scores + ((size_t)n * C + cf) * K, *st = scores + ((size_t)n * C + ct) * K;
     const int64_t *idf = inds + ((size_t)n * C + cf) * K, *idt = inds + ((size_t)n * C + ct) * K;
 
-    for (int m = lane; m < K; m += 64) {
-        const int64_t id = idt[m];
-        int64_t x = id % W, y = id / W;
-        const float s = st[m];
-        if (s < thre) { x -= 100000; y -= 100000; }  // collect.py:253
-        tx[m] = (float)x;
-        ty[m] = (float)y;
-        ts[m] = s;
-        ti[m] = (int)id;
+    for (int m = lane; m < Kp; m += 64) {
+        if (m < K) {
+            const int64_t id = idt[m];
+            int64_t x = id % W, y = id / W;
+            const float s = st[m];
+            if (s < thre) { x -= 100000; y -= 100000; }  // collect.py:253
+            txy[m] = make_float2((float)x, (float)y);
+            ts[m] = s;
+            ti[m] = (int)id;
+        } else {
+            txy[m] = make_float2(INFINITY, INFINITY);    // padding never wins the argmin
+        }
     }
     __syncthreads();
 
@@ -86,12 +91,17 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
         const float gx = xf + ox * resize, gy = yf + oy * resize;  // collect.py:152
         int best = 0;
         float bd = INFINITY;
-        for (int m = 0; m < K; ++m) {  // collect.py:171-177
-            const float dx = gx - tx[m], dy = gy - ty[m];
-            const float d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
-            if (d < bd) { bd = d; best = m; }
+        for (int m0 = 0; m0 < Kp; m0 += 4) {  // collect.py:171-177; 4 candidates per pair of wide LDS reads
+            const float4 a = *reinterpret_cast<const float4 *>(txy + m0), b = *reinterpret_cast<const float4 *>(txy + m0 + 2);
+            const float cx[4] = {a.x, a.z, b.x, b.z}, cy[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = gx - cx[j], dy = gy - cy[j];
+                const float d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+                if (d < bd) { bd = d; best = m0 + j; }   // strict <: first minimum wins
+            }
         }
-        const float x2 = tx[best], y2 = ty[best], s2 = ts[best];
+        const float x2 = txy[best].x, y2 = txy[best].y, s2 = ts[best];
         const float lx = xf - x2, ly = yf - y2;
         float len = sqrtf(__builtin_fmaf(ly, ly, lx * lx));
         len = len < min_len ? min_len : len;                        // collect.py:204-205
@@ -117,7 +127,7 @@ OG_API int og_collect_limbs_f32(const float *scores, const int64_t *inds, const 
     OG_REQUIRE(!off_is_lowres || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
     OG_REQUIRE((long)H * W < (1l << 31), OG_EINVAL, "%s: plane too large", name);
     OG_REQUIRE(k <= 2048, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
-    hipLaunchKernelGGL(collect_limbs_kernel, dim3(N * L), dim3(64), (size_t)k * 16, (hipStream_t)stream, scores, inds,
+    hipLaunchKernelGGL(collect_limbs_kernel, dim3(N * L), dim3(64), (size_t)((k + 3) & ~3) * 16, (hipStream_t)stream, scores, inds,
                        offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs);
     OG_LAUNCH_CHECK(name);
     return OG_OK;

@@ -439,56 +439,54 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 //   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
 template <bool NMS_MODE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
                    int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
                    const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
                    float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const int plane = blockIdx.x, lane = threadIdx.x;
+    const int plane = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n_all = nbands * k;
     uint64_t *all = lds64;             // n_all keys (0 = empty slot)
-    uint64_t *flt = lds64 + n_all;     // filtered keys
+    uint64_t *flt = lds64 + n_all;     // subset, then filtered keys
     __shared__ uint64_t s_bound;
-    __shared__ int s_cnts[256];
+    __shared__ int s_nf;
     const uint64_t *gk = band_keys + (size_t)plane * n_all;
     const int *gc = band_cnt + (size_t)plane * nbands;
     float *os = out_scores + (size_t)plane * k;
     int64_t *oi = out_inds + (size_t)plane * k;
 
+    // keys and band counts are fetched together (one memory round trip), masked afterwards
+    for (int i = tid; i < n_all; i += blockDim.x) {
+        const uint64_t key = gk[i];
+        const int c = gc[i / k];
+        all[i] = (i % k < c) ? key : 0ull;
+    }
+    if (tid == 0) { s_bound = 0ull; s_nf = 0; }
     if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
-        for (int i = lane; i < nbands; i += 64) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
-    if (blockIdx.x == 0 && lane == 0) *ws_magic = hist_all ? magic : 0ull;
-    for (int b = lane; b < nbands; b += 64) s_cnts[b] = gc[b];
-    if (lane == 0) s_bound = 0ull;
-    __syncthreads();
-    for (int i = lane; i < n_all; i += 64) all[i] = (i % k < s_cnts[i / k]) ? gk[i] : 0ull;
+        for (int i = tid; i < nbands; i += blockDim.x) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
+    if (blockIdx.x == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
     __syncthreads();
     // A) k-th largest of the subset {first t_sub keys of each band}
     const int n_sub = nbands * t_sub;
-    uint64_t *subk = flt;  // the filtered list is built later: reuse its space
-    for (int i = lane; i < n_sub; i += 64) subk[i] = all[(i / t_sub) * k + i % t_sub];
+    for (int i = tid; i < n_sub; i += blockDim.x) flt[i] = all[(i / t_sub) * k + i % t_sub];
     __syncthreads();
-    for (int i = lane; i < n_sub; i += 64) {
-        const uint64_t mine = subk[i];
-        if (mine != 0ull && og_count_greater(subk, n_sub, mine) == k - 1) s_bound = mine;
+    for (int i = tid; i < n_sub; i += blockDim.x) {
+        const uint64_t mine = flt[i];
+        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) s_bound = mine;
     }
     __syncthreads();
     const uint64_t bound = s_bound;
-    // B) keys >= bound
-    int nf = 0;
-    for (int i0 = 0; i0 < n_all; i0 += 64) {
-        const int i = i0 + lane;
-        const uint64_t key = (i < n_all) ? all[i] : 0ull;
-        const bool keep = key != 0ull && key >= bound;
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) flt[nf + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
-        nf += __builtin_popcountll(mask);
+    // B) keys >= bound (order does not matter: ranks are recomputed)
+    for (int i = tid; i < n_all; i += blockDim.x) {
+        const uint64_t key = all[i];
+        if (key != 0ull && key >= bound) flt[atomicAdd(&s_nf, 1)] = key;
     }
     __syncthreads();
+    const int nf = s_nf;
     // C) rank and emit
-    for (int i = lane; i < nf; i += 64) {
+    for (int i = tid; i < nf; i += blockDim.x) {
         const uint64_t mine = flt[i];
         const int rank = og_count_greater(flt, nf, mine);
         if (rank < k) {
@@ -497,7 +495,7 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
         }
     }
     int t = min(nf, k);
-    if (NMS_MODE && t < k) {
+    if (NMS_MODE && t < k && tid < 64) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
         const float *p = in + (size_t)plane * H * W;
@@ -547,7 +545,7 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     if (p->nwaves > kMaxWaves) return false;
     p->panel_strips = (strips + p->nwaves - 1) / p->nwaves;
     int rows = env_int("OG_NMS_ROWS", 80);
-    rows = max(rows, (H + 255) / 256);  // the merge kernel indexes at most 256 bands
+    rows = max(rows, (H + 63) / 64);    // the slot table is scanned by one wave: at most 64 bands
     rows = min(rows, H);
     p->rows = rows;
     p->nbands = (H + rows - 1) / rows;
@@ -601,7 +599,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
-    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(64), mlds, stream, keys, cnts, hist,
+    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
                        magic, p.magic, in, H, W, k, p.nbands, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
