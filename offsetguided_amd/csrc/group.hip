@@ -77,15 +77,21 @@ __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairw
     return res;
 }
 
+// GSUB / LLDS are template flags, not runtime selects: a pointer that may be LDS *or* global is a
+// generic pointer, and every access through it becomes a flat_load (several times the latency of
+// ds_read, and it ties LDS traffic to vmcnt).  With static address spaces the table is plain ds_*.
+template <bool GSUB, bool LLDS>
 __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
 {
-    extern __shared__ float lds[];
-    __shared__ int s_nv, s_kk, s_anyA, s_anyB, s_anyQ, s_M, s_P, s_overflow, s_kept;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_nv, s_kk, s_anyA, s_anyB, s_anyQ, s_M, s_P, s_overflow, s_kept, s_new0, s_nnew;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = A.K, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax;
-    // ---- LDS carve-up ----
-    float *p = lds;
+    // ---- LDS carve-up (pure pointer arithmetic: an integer round trip for alignment would turn
+    // everything carved after it into generic pointers, i.e. flat_load instead of ds_read) ----
+    double *r_score = reinterpret_cast<double *>(lds);        // 8-byte items first: the base is 16-byte aligned
+    float *p = reinterpret_cast<float *>(r_score + mmax);
     float *c_lim = p;            p += (size_t)K * 11;      // unique limb rows: x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
     float *c_score = p;          p += K;                   // per candidate: score (staging for the sort)
     int *c_i2 = (int *)p;        p += K;                   // per candidate: to-index
@@ -93,26 +99,28 @@ greedy_group_kernel(GroupArgs A)
     int *c_uq = (int *)p;        p += K;                   // sorted, de-duplicated
     int *c_n1 = (int *)p;        p += K;                   // rows with ms==1 per column
     int *c_n2 = (int *)p;        p += K;                   // rows with ms==2 per column
+    int *c_srt = (int *)p;       p += K;                   // to-index in sorted order
+    int *c_dup = (int *)p;       p += K;                   // sorted position repeats an earlier to-index
     int *order = (int *)p;       p += mmax;                // logical position -> physical row
     int *r_a = (int *)p;         p += mmax;                // phase-A column per logical row / merge partner
     int *r_b = (int *)p;         p += mmax;                // phase-B last column per logical row / deleted flag
-    float *s_vals = p;           p += 64 * 17;             // per-lane scratch for the final mean
-    double *r_score = (double *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
-    p = (float *)(r_score + mmax);
+    float *s_vals = p;           p += kThreads * 17;       // per-thread scratch for the final mean
     float *s_limbs = p;
-    if (A.limbs_in_lds) p += (size_t)A.L * K * 13;
-    float *sub = A.gsub ? A.gsub + (size_t)img * mmax * rowf : p;
+    if (LLDS) p += (size_t)A.L * K * 13;
+    float *sub_lds = p;
+    float *sub_glb = A.gsub + (size_t)img * mmax * rowf;
+#define sub (GSUB ? sub_glb : sub_lds)
 #define SUBP(ph, j, f) sub[((size_t)(ph) * nkp + (j)) * 6 + (f)]
 #define LIM(c, f) c_lim[(size_t)(c) * 11 + (f)]
 
     if (tid == 0) { s_M = 0; s_P = 0; s_overflow = 0; }
     __syncthreads();
-    const float *limbs = A.limbs + (size_t)img * A.L * K * 13;
-    if (A.limbs_in_lds) {  // one coalesced pass instead of two dependent global reads per limb type
+    const float *limbs_glb = A.limbs + (size_t)img * A.L * K * 13;
+    if (LLDS) {  // one coalesced pass instead of two dependent global reads per limb type
         const int n = A.L * K * 13;
-        for (int i = tid; i < n; i += kThreads) s_limbs[i] = limbs[i];
-        limbs = s_limbs;
+        for (int i = tid; i < n; i += kThreads) s_limbs[i] = limbs_glb[i];
     }
+#define limbs (LLDS ? (const float *)s_limbs : limbs_glb)
     __syncthreads();
 
     K3_STAMP_INIT;
@@ -134,31 +142,33 @@ greedy_group_kernel(GroupArgs A)
         K3_STAMP(0);
         const int nv = s_nv;
         if (nv == 0) continue;  // uniform
-        // ---- 2. stable sort by score descending (:232), rank by counting ----
-        for (int k = tid; k < K; k += kThreads) {
-            const float s = c_score[k];
-            if (s != -INFINITY) {
-                int rank = 0;
-                for (int j = 0; j < K; ++j) {
-                    const float o = c_score[j];
-                    rank += (o != -INFINITY) && (o > s || (o == s && j < k));
-                }
-                c_ord[rank] = k;
-            }
+        // ---- 2. stable sort by score descending (:232): rank by counting over (k, j) cells ----
+        for (int k = tid; k < K; k += kThreads) c_ord[k] = 0;   // reused as the rank accumulator
+        __syncthreads();
+        for (int cell = tid; cell < K * K; cell += kThreads) {
+            const int k = cell / K, j = cell - k * K;
+            const float s = c_score[k], o = c_score[j];
+            if (s != -INFINITY && o != -INFINITY && (o > s || (o == s && j < k))) atomicAdd(&c_ord[k], 1);
         }
         __syncthreads();
-        K3_STAMP(1);
-        // ---- 3. keep the first occurrence of every to-index (:233-239): wave 0 ----
+        int my_rank = -1;
+        if (tid < K && c_score[tid] != -INFINITY) my_rank = c_ord[tid];
+        __syncthreads();
+        if (my_rank >= 0) { c_ord[my_rank] = tid; c_srt[my_rank] = c_i2[tid]; }
+        __syncthreads();
+        // ---- 3. keep the first occurrence of every to-index (:233-239): (p, q<p) cells, then wave-0 compaction ----
+        for (int p0 = tid; p0 < nv; p0 += kThreads) c_dup[p0] = 0;
+        __syncthreads();
+        for (int cell = tid; cell < nv * nv; cell += kThreads) {
+            const int pp = cell / nv, q = cell - pp * nv;
+            if (q < pp && c_srt[q] == c_srt[pp]) c_dup[pp] = 1;
+        }
+        __syncthreads();
         if (wave == 0) {
             int kk = 0;
             for (int p0 = 0; p0 < nv; p0 += 64) {
                 const int pp = p0 + lane;
-                bool keep = false;
-                if (pp < nv) {
-                    const int t = c_i2[c_ord[pp]];
-                    keep = true;
-                    for (int q = 0; q < pp; ++q) keep &= (c_i2[c_ord[q]] != t);
-                }
+                const bool keep = pp < nv && !c_dup[pp];
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
                 if (keep) c_uq[kk + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c_ord[pp];
                 kk += __builtin_popcountll(mask);
@@ -221,10 +231,12 @@ greedy_group_kernel(GroupArgs A)
                 const int b = a + 1 + (pi - a * (2 * m0 - a - 1) / 2);
                 const int pa = order[a], pb = order[b];
                 int cnt = 0;
-                for (int j = 0; j < nkp; ++j) {
-                    const int ia = (int)SUBP(pa, j, 5), ib = (int)SUBP(pb, j, 5);
-                    cnt += (ia == ib && ia != -1);
-                }
+#pragma unroll
+                for (int j = 0; j < 17; ++j)  // all 34 LDS reads issue back to back
+                    if (j < nkp) {
+                        const int ia = (int)SUBP(pa, j, 5), ib = (int)SUBP(pb, j, 5);
+                        cnt += (ia == ib && ia != -1);
+                    }
                 if (cnt == 2) { atomicMax(&r_a[a], b); r_b[b] = 1; s_anyQ = 1; }
             }
             __syncthreads();
@@ -255,9 +267,9 @@ greedy_group_kernel(GroupArgs A)
             }
         }
         K3_STAMP(5);
-        // ---- 6. unmatched limbs start new rows (:166-177): wave 0 assigns slots ----
+        // ---- 6. unmatched limbs start new rows (:166-177): wave 0 assigns slots, everyone fills ----
         if (wave == 0) {
-            int M = s_M, P = s_P;
+            int M = s_M, P = s_P, n_tot = 0;
             for (int c0 = 0; c0 < kk; c0 += 64) {
                 const int c = c0 + lane;
                 bool fresh = false;
@@ -268,17 +280,24 @@ greedy_group_kernel(GroupArgs A)
                 const int off = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 if (fresh) {
                     order[M + off] = P + off;
-                    float *r = sub + (size_t)(P + off) * rowf;
-                    for (int f = 0; f < rowf; ++f) r[f] = -1.f;
-                    r[jf * 6 + 5] = LIM(c, 9); r[jt * 6 + 5] = LIM(c, 10);
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) { r[jf * 6 + f] = LIM(c, f); r[jt * 6 + f] = LIM(c, 4 + f); }
-                    r[jf * 6 + 4] = LIM(c, 8); r[jt * 6 + 4] = LIM(c, 8);
+                    c_srt[n_tot + off] = c;      // column of the (n_tot+off)-th new row
                 }
                 M += n_new;
                 P += n_new;
+                n_tot += n_new;
             }
-            if (lane == 0) { s_M = M; s_P = P; }
+            if (lane == 0) { s_new0 = s_P; s_nnew = n_tot; s_M = M; s_P = P; }
+        }
+        __syncthreads();
+        {
+            const int n_new = s_overflow ? 0 : s_nnew, p_first = s_new0;
+            for (int e = tid; e < n_new * rowf; e += kThreads) {
+                const int r = e / rowf, jf6 = e - r * rowf, j = jf6 / 6, f = jf6 - j * 6, c = c_srt[r];
+                float v = -1.f;
+                if (j == jf) v = (f < 4) ? LIM(c, f) : (f == 4 ? LIM(c, 8) : LIM(c, 9));
+                else if (j == jt) v = (f < 4) ? LIM(c, 4 + f) : (f == 4 ? LIM(c, 8) : LIM(c, 10));
+                sub[(size_t)(p_first + r) * rowf + e - r * rowf] = v;
+            }
         }
         __syncthreads();
         K3_STAMP(6);
@@ -293,27 +312,19 @@ greedy_group_kernel(GroupArgs A)
     const int M = s_M;
     if (tid == 0) s_kept = 0;
     __syncthreads();
-    if (wave == 0) {
-        int kept = 0;
-        for (int mb = 0; mb < M; mb += 64) {
-            const int m = mb + lane;
-            bool keep = false;
-            if (m < M) {
-                const int ph = order[m];
-                float *v = s_vals + lane * 17;
-                int n = 0;
-                for (int j = 0; j < nkp; ++j) {
-                    const float x = SUBP(ph, j, A.sort_dim);
-                    if (x > 0.f) v[n++] = x;
-                }
-                const double score = (double)np_sum17(v, n) / (double)n;  // 0/0 -> NaN -> kept, like the reference
-                keep = !(score < A.person_thre);
-                r_score[m] = score;
-                r_b[m] = keep ? 0 : 1;
-            }
-            kept += __builtin_popcountll(__builtin_amdgcn_ballot_w64(keep));
+    for (int m = tid; m < M; m += kThreads) {
+        const int ph = order[m];
+        float *v = s_vals + (size_t)tid * 17;
+        int n = 0;
+        for (int j = 0; j < nkp; ++j) {
+            const float x = SUBP(ph, j, A.sort_dim);
+            if (x > 0.f) v[n++] = x;
         }
-        if (lane == 0) s_kept = kept;
+        const double score = (double)np_sum17(v, n) / (double)n;  // 0/0 -> NaN -> kept, like the reference
+        const bool keep = !(score < A.person_thre);
+        r_score[m] = score;
+        r_b[m] = keep ? 0 : 1;
+        if (keep) atomicAdd(&s_kept, 1);
     }
     __syncthreads();
     float *out = A.poses + (size_t)img * mmax * rowf;
@@ -335,13 +346,15 @@ greedy_group_kernel(GroupArgs A)
     if (tid == 0) { A.counts[img] = s_kept; A.status[img] = 0; }
 #undef SUBP
 #undef LIM
+#undef sub
+#undef limbs
 }
 
 constexpr size_t kLdsLimit = 159 * 1024;  // 160 KiB per CU minus the static __shared__ words
 
 size_t staging_bytes(int K, int mmax)
 {
-    return ((size_t)K * 11 + (size_t)K * 6 + (size_t)mmax * 3 + 64 * 17) * 4 + 8 + (size_t)mmax * 8;
+    return ((size_t)K * 11 + (size_t)K * 8 + (size_t)mmax * 3 + kThreads * 17) * 4 + 8 + (size_t)mmax * 8;
 }
 
 }  // namespace
@@ -362,7 +375,7 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
     OG_REQUIRE(N > 0 && L > 0 && k > 0 && mmax > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE(n_kp > 0 && n_kp <= 17, OG_EUNSUPPORTED, "%s: n_kp=%d (max 17)", name, n_kp);
     OG_REQUIRE(sort_dim >= 0 && sort_dim < 6, OG_EINVAL, "%s: sort_dim", name);
-    OG_REQUIRE(k <= 1024, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
+    OG_REQUIRE(k <= kThreads, OG_EUNSUPPORTED, "%s: k=%d too large (max %d)", name, k, kThreads);
     OG_REQUIRE(mmax <= 4096, OG_EUNSUPPORTED, "%s: mmax=%d too large", name, mmax);
     GroupArgs a;
     a.limbs = limbs; a.jf = jf; a.jt = jt; a.L = L; a.K = k; a.nkp = n_kp; a.use_scale = use_scale;
@@ -381,14 +394,16 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
         OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: mmax=%d too large", name, mmax);
         a.gsub = (float *)workspace;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)greedy_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kLdsLimit);
+    void (*kern)(GroupArgs) = a.gsub ? (a.limbs_in_lds ? greedy_group_kernel<true, true> : greedy_group_kernel<true, false>)
+                                     : (a.limbs_in_lds ? greedy_group_kernel<false, true> : greedy_group_kernel<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int variant = (a.gsub ? 2 : 0) + (a.limbs_in_lds ? 1 : 0);
+    if (!attr_set[variant]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-        attr_set = true;
+        attr_set[variant] = true;
     }
-    hipLaunchKernelGGL(greedy_group_kernel, dim3(N), dim3(kThreads), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(N), dim3(kThreads), lds, (hipStream_t)stream, a);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
