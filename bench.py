@@ -216,8 +216,9 @@ def main():
                           f"1 thread ({c['decode_s_per_img'] * 1e3:.1f} ms/img)",
                 'decoder_ms_per_img': round(c['decode_s_per_img'] * 1e3, 2)}
         print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

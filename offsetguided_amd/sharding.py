@@ -18,7 +18,8 @@ def env_rank():
 def init(backend=None, device=None):
     """Join the process group described by the torchrun environment (no-op for one process)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('OG_FORCE_DIST') == '1'   # exercise the process-group path with one rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
         kwargs = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
