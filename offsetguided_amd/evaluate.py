@@ -1,0 +1,179 @@
+"""Inference harness with the reference evaluate.py surface (evaluate_cli :49-122, run_images
+:125-300, validation :303-328), MI355X-native underneath:
+
+  images -> models.InferenceEngine (bf16 NHWC, HIP graph) -> decoder.PostProcess.submit (HIP kernels,
+  batch i+1's backbone is queued before batch i's poses are collected) -> annotations_inverse ->
+  COCO-style result dicts.
+
+COCO data loading and pycocotools are not part of this path: `run_images` takes any iterable of
+(images, annos, metas) batches (the reference's collate format, data/factory.py:23-35) and falls back
+to synthetic batches; `validation` needs pycocotools and raises if it is absent.
+"""
+import argparse
+import json
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import decoder, models
+from .utils import AverageMeter
+
+LOG = logging.getLogger(__name__)
+
+ANNOTATIONS_VAL = 'data/link2COCO2017/annotations/person_keypoints_val2017.json'
+IMAGE_DIR_VAL = 'data/link2COCO2017/val2017'
+ANNOTATIONS_TESTDEV = 'data/link2COCO2017/annotations_trainval_info/image_info_test-dev2017.json'
+ANNOTATIONS_TEST = 'data/link2COCO2017/annotations_trainval_info/image_info_test2017.json'
+IMAGE_DIR_TEST = 'data/link2COCO2017/test2017/'
+
+
+def evaluate_cli(argv=None):
+    """Same flags as the reference (apex flags are accepted and ignored: bf16 is built in)."""
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    g = parser.add_argument_group('logging')
+    g.add_argument('--debug', default=False, action='store_true')
+    g.add_argument('-q', '--quiet', default=False, action='store_true')
+    models.net_cli(parser)
+    decoder.decoder_cli(parser)
+    parser.add_argument('--dump-name', default='hourglass104_mi355x', type=str, help='detection file name')
+    parser.add_argument('--dataset', choices=('val', 'test', 'test-dev'), default='val')
+    parser.add_argument('--batch-size', default=8, type=int)
+    parser.add_argument('--long-edge', default=640, type=int, help='long edge of input images')
+    parser.add_argument('--fixed-height', action='store_true', default=False)
+    parser.add_argument('--flip-test', action='store_true', default=False, help='flip augmentation during testing')
+    parser.add_argument('--cat-flip-offset', action='store_true', default=False)
+    parser.add_argument('--loader-workers', default=8, type=int)
+    parser.add_argument('--all-images', default=False, action='store_true')
+    parser.add_argument('--resume', '-r', action='store_true', default=False, help='load --checkpoint-whole')
+    parser.add_argument('--checkpoint-path', '-p', default='link2checkpoints_storage')
+    parser.add_argument('--show-detected-poses', action='store_true', default=False)
+    g = parser.add_argument_group('apex configuration (accepted for command-line compatibility, unused)')
+    g.add_argument('--local_rank', default=0, type=int)
+    g.add_argument('--opt-level', type=str, default='O2')
+    g.add_argument('--keep-batchnorm-fp32', type=str, default=None)
+    g.add_argument('--loss-scale', type=str, default=None)
+    g.add_argument('--channels-last', default=False, action='store_true')
+    g.add_argument('--print-freq', '-f', default=10, type=int, metavar='N')
+    args = parser.parse_args(argv)
+    args.image_dir, args.annotation_file = {
+        'val': (IMAGE_DIR_VAL, ANNOTATIONS_VAL), 'test': (IMAGE_DIR_TEST, ANNOTATIONS_TEST),
+        'test-dev': (IMAGE_DIR_TEST, ANNOTATIONS_TESTDEV)}[args.dataset]
+    if args.dataset in ('test', 'test-dev'):
+        args.all_images = True
+    return args
+
+
+def annotations_inverse(keypoints, meta):
+    """Poses from network-input coordinates back to the original image (transforms/preprocess.py:33-63):
+    un-pad (offset), un-scale, keypoint scales / sqrt(sx*sy)."""
+    kp = np.array(keypoints, copy=True)
+    kp[:, :, 0] += meta['offset'][0]
+    kp[:, :, 1] += meta['offset'][1]
+    kp[:, :, 0] /= meta['scale'][0]
+    kp[:, :, 1] /= meta['scale'][1]
+    kp[:, :, 3] /= np.sqrt(np.prod(meta['scale']))
+    if meta.get('hflip'):
+        raise Exception('this should not happen. please have a check here, not implemented actually!')
+    return kp
+
+
+def poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids):
+    """Append one image's COCO keypoint results (evaluate.py:227-265); returns the inverse-mapped poses."""
+    subset = annotations_inverse(image_poses, image_meta)
+    image_id = image_meta['image_id']
+    result_image_ids.append(image_id)
+    subset[:, :, :2] = np.around(subset[:, :, :2], 2)
+    for person in subset.astype(float):
+        triples, vis = [], []
+        for x, y, v in person[:, :3]:
+            vis.append(v)
+            triples += [x, y, 1 if x > 0 or y > 0 else 0]
+        result_keypoints.append({'image_id': image_id, 'category_id': 1, 'keypoints': triples,
+                                 'score': sum(vis) / len(vis)})
+    if not len(subset):
+        result_keypoints.append({'image_id': image_id, 'category_id': 1, 'keypoints': np.zeros((17 * 3,)).tolist(),
+                                 'score': 0.01})
+    return subset
+
+
+def synthetic_loader(n_batches, batch_size, size, device, seed=0):
+    """Stand-in for DataLoader(CocoKeypoints): random normalised images + identity metas."""
+    g = torch.Generator(device).manual_seed(seed)
+    for b in range(n_batches):
+        images = torch.randn(batch_size, 3, size, size, device=device, generator=g)
+        metas = [{'image_id': b * batch_size + i, 'offset': np.array([0.0, 0.0]), 'scale': np.array([1.0, 1.0]),
+                  'hflip': False} for i in range(batch_size)]
+        yield images, [None] * batch_size, metas
+
+
+def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
+    """The hot loop of evaluate.py:207-298.  Returns (result_keypoints, result_image_ids)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('run_images needs a HIP device (offsetguided_amd has no CPU path)')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    result_keypoints, result_image_ids = [], []
+    if model is None:
+        model, _ = models.model_factory(args)
+        if args.resume:
+            model, *_ = models.load_model(model, args.checkpoint_whole, optimizer=None, resume_optimizer=False,
+                                          drop_layers=False, load_amp=False)
+    processor = decoder.decoder_factory(args)
+    if data_loader is None:
+        data_loader = synthetic_loader(n_synthetic_batches, args.batch_size, args.long_edge, dev)
+    engine, batch_time, end, pending = None, AverageMeter(), time.time(), None
+
+    def collect(handle):
+        poses, metas = handle
+        for image_poses, image_meta in zip(poses.result(), metas):
+            poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids)
+
+    for batch_idx, (images, _, metas) in enumerate(data_loader):
+        images = images.to(dev, non_blocking=True)
+        if args.flip_test:
+            images = torch.cat((images, torch.flip(images, [-1])))
+        if engine is None or engine.shape != tuple(images.shape):
+            engine = models.InferenceEngine(model, *images.shape[:1], images.shape[2], images.shape[3], device=dev)
+        outputs = engine(images)
+        handle = (processor.submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
+        if pending is not None:
+            collect(pending)
+        pending = handle
+        if batch_idx % args.print_freq == 0:
+            torch.cuda.synchronize()
+            batch_time.update((time.time() - end) / args.print_freq)
+            end = time.time()
+            print('==================> [{0}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tSpeed {1:.3f} ({2:.3f})'.format(
+                batch_idx, args.batch_size / batch_time.val, args.batch_size / batch_time.avg, bt=batch_time))
+    if pending is not None:
+        collect(pending)
+    return result_keypoints, result_image_ids
+
+
+def validation(args, data_loader=None):
+    """run_images + COCO keypoint evaluation (evaluate.py:303-328); needs pycocotools."""
+    try:
+        from pycocotools.coco import COCO
+        from pycocotools.cocoeval import COCOeval
+    except ImportError as e:
+        raise ImportError('validation() needs pycocotools; run_images() does not') from e
+    res_file = 'data/link2COCO2017/results/person_keypoints_%s_%s_results.json' % (args.dataset, args.dump_name)
+    os.makedirs(os.path.dirname(res_file), exist_ok=True)
+    coco_gt = COCO(args.annotation_file)
+    results, ids = run_images(args, data_loader)
+    json.dump(results, open(res_file, 'w'))
+    coco_eval = COCOeval(coco_gt, coco_gt.loadRes(res_file), iouType='keypoints')
+    coco_eval.params.imgIds = ids
+    coco_eval.evaluate()
+    coco_eval.accumulate()
+    coco_eval.summarize()
+    return coco_eval
+
+
+if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO)
+    a = evaluate_cli()
+    kps, ids = run_images(a)
+    print(f'{len(ids)} images, {len(kps)} detections')
