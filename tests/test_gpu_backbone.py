@@ -67,3 +67,15 @@ def test_engine_matches_eager_fp32(dev):
             err = (o - r).abs().max().item() / r.abs().max().item()
             assert err < 0.05, f"head {h}: relative error {err}"
         assert out[0][0][0] is None and out[0][1] == [[], []]     # reference nesting, unused stack skipped
+
+
+def test_run_images_synthetic(dev):
+    """evaluate.run_images end to end on synthetic batches (engine + pipelined decode + result dicts)."""
+    from offsetguided_amd import evaluate
+    a = evaluate.evaluate_cli(['--no-pretrain', '--topk', '16', '--thre-hmp', '0.04', '--person-thre', '0.04',
+                               '--dist-max', '40', '--long-edge', '128', '--batch-size', '2', '--flip-test',
+                               '--print-freq', '1'])
+    results, ids = evaluate.run_images(a, n_synthetic_batches=3)
+    assert ids == list(range(6))
+    assert all(len(r['keypoints']) == 51 and r['category_id'] == 1 for r in results)
+    assert {r['image_id'] for r in results} == set(range(6))       # every image reports at least the fallback entry
