@@ -44,6 +44,9 @@
 
 namespace {
 
+#ifndef OG_K1_LOAD_AUX
+#define OG_K1_LOAD_AUX 2  // nt: the heatmap is streamed once (+8% read bandwidth measured on MI355X)
+#endif
 constexpr int kPrefetch = 4;      // rows in flight per lane
 constexpr int kInterior = 62;     // interior lanes per wave panel
 constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
@@ -109,7 +112,7 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
         Px<VEC> r;
         if constexpr (VEC == 4) {
             typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, OG_K1_LOAD_AUX));
             r.c[0] = t.x; r.c[1] = t.y; r.c[2] = t.z; r.c[3] = t.w;
         } else {
             r.c[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
@@ -201,6 +204,7 @@ struct WaveSeg {
     int tau_bits;
     float tau_f;
     int *hist;            // plane histogram (global) or nullptr
+    int npush = 0;        // debug statistics (OG_K1_DEBUG)
 
     __device__ __forceinline__ void set_tau(float t)
     {
@@ -241,6 +245,7 @@ struct WaveSeg {
             if (NMS_MODE && hist) atomicAdd(hist + hist_bin(__builtin_bit_cast(int, v)), 1);
         }
         cnt += n;
+        npush += n;
     }
 };
 
@@ -249,7 +254,7 @@ template <int VEC, bool NMS_MODE, int PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * kMaxWaves)
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
                  int *__restrict__ hist_all, const uint64_t *__restrict__ ws_magic, uint64_t magic,
-                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded)
+                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded, int helper)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
     // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
@@ -257,7 +262,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     int *s_hist = reinterpret_cast<int *>(smem + (size_t)(blockDim.x >> 6) * 2 * cap);
     int *s_cnt = s_hist + kHistBins;
     int *s_slot = s_cnt + kMaxWaves;   // which of the 2*nwaves key buffers holds wave w's final list
-    int *s_tau_p = s_slot + kMaxWaves;
+    int *s_tau_p = s_slot + kMaxWaves;    // followed by the streaming-waves-done counter
 #define s_tau (*s_tau_p)
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
@@ -274,96 +279,98 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     if (NMS_MODE) { seg.tau_bits = 1; seg.tau_f = 0.f; }  // bits >= 1  <=>  v > +0
     else seg.set_tau(-INFINITY);
     if (ABL == 2) seg.set_tau(0.035f);  // harness: what a perfect plane-wide threshold would buy
-    // Plane-wide admission threshold without atomics.  Each workgroup counts its candidates in an
-    // LDS histogram (ds_add).  After every iteration (PF rows) one wave -- the duty rotates -- scans it and
-    //   * publishes E_t = lower edge of the bin holding the band's t-th best so far,
-    //     t = ceil(k / nbands), into the band's own slot of a per-plane table (plain sc1 store);
-    //   * reads all slots of the plane (one sc1 dword per lane): if every band has published,
-    //     min_b E_t(b) is a lower bound on the plane's k-th best (each band owns >= t candidates
-    //     above its own E_t, hence nbands*t >= k above the minimum);
-    //   * also takes the band's own k-th best edge;
-    // and hands max(those) to the other waves through LDS.  Slots only grow, so stale reads are
-    // merely weaker bounds: no ordering is needed and the top-k stays exact.  The table is trusted
-    // only if the workspace carries this geometry's magic word (zeroed + stamped by the merge
-    // kernel of the previous call).
-    int *gslot = (NMS_MODE && hist_all && *ws_magic == magic) ? hist_all + (size_t)plane * nbands : nullptr;
+    // Plane-wide admission threshold, no atomics on global memory and NO vector-memory operation in
+    // the streaming waves' loop (any conditional one makes the compiler drain the row prefetch queue
+    // with vmcnt(0) every iteration -- ~5 us each under load).  The streaming waves only ds_add their
+    // candidates into an LDS histogram and read the current threshold from LDS.  A HELPER wave (the
+    // last wave of the workgroup, present when `helper` is set) loops beside them:
+    //   scan the LDS histogram (DPP prefix sum) -> E_k = edge of the bin with the band's k-th best,
+    //   E_t = edge of its t-th best (t = k/4) -> publish E_t in the band's slot of a per-plane table
+    //   (sc1 store) -> read all slots (sc1 load): the 4th largest published edge bounds the plane's
+    //   k-th best (4 bands x t >= k candidates above it) -> s_tau = max(...) in LDS -> sleep.
+    // Slots only grow and every bound is a true lower bound whatever the timing, so the top-k stays
+    // exact.  The table is trusted only if the workspace carries this geometry's magic word.
+    const int hmode = helper;   // bit 0: helper wave present; bit 3: debug statistics (tools/)
+    helper &= 1;
+    const int nstream = (blockDim.x >> 6) - helper;   // streaming waves
+    int *gslot = (NMS_MODE && helper && *ws_magic == magic) ? hist_all + (size_t)plane * nbands : nullptr;
     seg.hist = gslot ? s_hist : nullptr;
+    int *s_done = s_tau_p + 1;
     if (gslot) {
         for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
-        if (threadIdx.x == 0) s_tau = 1;
+        if (threadIdx.x == 0) { s_tau = 1; *s_done = 0; }
         __syncthreads();
     }
-    const __amdgpu_buffer_rsrc_t srsrc =
-        __builtin_amdgcn_make_buffer_rsrc(gslot ? gslot : hist_all, 0, gslot ? nbands * 4 : 0, 0x00020000);
     const int lane_id = threadIdx.x & 63;
-    const int t_band = (k + 3) / 4;  // any 4 finished bands give a bound
-    const int nwaves_ = blockDim.x >> 6;
-    int iter = 0, published = 0;
-    bool fetched = false;
-    if (gslot) {
-        // bound from the bands that already finished (earlier dispatch rounds): the `need` largest
-        // published E_t values cover need*t >= k candidates, so their minimum bounds the k-th best
-        const int sv = __builtin_amdgcn_raw_buffer_load_b32(srsrc, lane_id * 4, 0, 16);  // lanes >= nbands read 0
-        const int need = (k + t_band - 1) / t_band;
-        int rank = 0;  // number of slots strictly greater (ties by lane) than this lane's
-        for (int b = 0; b < nbands; ++b) {
-            const int o = __builtin_amdgcn_readlane(sv, b);
-            rank += (o > sv) || (o == sv && b < lane_id);
-        }
-        const uint64_t pick = __builtin_amdgcn_ballot_w64(lane_id < nbands && sv > 0 && rank == need - 1);
-        if (pick != 0ull) {
-            const int bound = __builtin_amdgcn_readlane(sv, __builtin_ctzll(pick));
-            if (bound > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, bound));
-            if (threadIdx.x == 0) atomicMax(&s_tau, bound);
+    if (helper && wave == nstream) {
+        if (gslot) {
+            const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(gslot, 0, nbands * 4, 0x00020000);
+            const int t_band = (k + 3) / 4, need = (k + t_band - 1) / t_band;
+            int published = 0;
+            for (;;) {
+                const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // lane l holds local bins 4l..4l+3; inclusive prefix over lanes by DPP, then suffix sums
+                int h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    h[j] = __hip_atomic_load(s_hist + 4 * lane_id + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int mine = h[0] + h[1] + h[2] + h[3];
+                int pre = mine;
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false);  // row_shr:1
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);  // row_shr:2
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);  // row_shr:4
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);  // row_shr:8
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+                pre += __builtin_amdgcn_update_dpp(0, pre, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+                const int total = __builtin_amdgcn_readlane(pre, 63);
+                const int suf = total - pre + mine;   // candidates in bins >= 4l
+                const int above = suf - mine;
+                auto edge_of = [&](int want) {        // lower edge (float bits) of the bin holding the want-th best
+                    const uint64_t ge = __builtin_amdgcn_ballot_w64(suf >= want);
+                    if (ge == 0ull) return 0;
+                    const int top = 63 - __builtin_clzll(ge);
+                    int bin = 4 * lane_id;
+                    if (above + h[3] >= want) bin += 3;
+                    else if (above + h[3] + h[2] >= want) bin += 2;
+                    else if (above + h[3] + h[2] + h[1] >= want) bin += 1;
+                    return __builtin_amdgcn_readlane(hist_edge_bits(bin), top);
+                };
+                const int e_k = edge_of(k), e_t = edge_of(t_band);
+                if (e_t > published) {
+                    published = e_t;
+                    // PLAIN store (stays in this XCD's L2; the sc1 loads below are L2-served): the bands of a
+                    // plane are mapped to one XCD, and a reader on another XCD merely sees an older, weaker
+                    // bound.  An sc1 (write-through) store here cost +35 us per launch on MI355X.
+                    if (lane_id == 0) __builtin_amdgcn_raw_buffer_store_b32(e_t, srsrc, band * 4, 0, 0);
+                }
+                // the `need`-th largest published slot (own slot: the value just computed)
+                int sv = __builtin_amdgcn_raw_buffer_load_b32(srsrc, lane_id * 4, 0, 16);  // lanes >= nbands read 0
+                if (lane_id == band) sv = published;
+                int rank = 0;
+                for (int b = 0; b < nbands; ++b) {
+                    const int o = __builtin_amdgcn_readlane(sv, b);
+                    rank += (o > sv) || (o == sv && b < lane_id);
+                }
+                const uint64_t pick = __builtin_amdgcn_ballot_w64(lane_id < nbands && sv > 0 && rank == need - 1);
+                int bound = e_k;
+                if (pick != 0ull) bound = max(bound, __builtin_amdgcn_readlane(sv, __builtin_ctzll(pick)));
+                if (lane_id == 0 && bound > 1) atomicMax(&s_tau, bound);
+                if (done >= nstream) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            // leave no vector-memory operation pending on this path: otherwise the compiler has to
+            // assume unknown outstanding counts at the head of the streaming loop below and drains
+            // the row prefetch queue (vmcnt(0)) on EVERY iteration of the streaming waves
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
     }
     auto iter_begin = [&](int) {
         if (!NMS_MODE || !gslot) return;
         const int t = s_tau;  // LDS broadcast
         if (t > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, t));
-        fetched = (iter % nwaves_) == wave;  // the refresh duty rotates over the waves: one per iteration
-        ++iter;
-    };
-    auto iter_end = [&](int) {
-        if (!NMS_MODE || !gslot) return;
-        // no global memory traffic in here: any extra (conditional) vector-memory operation in the
-        // streaming loop makes the compiler drain the row prefetch queue (vmcnt(0)) every iteration,
-        // which under a saturated memory system costs ~5 us each.  The slot table is read once when
-        // the workgroup starts and written once when it ends; this refresh only scans LDS.
-        if (!fetched) return;
-        // lane l holds local bins 4l..4l+3; inclusive prefix over lanes by DPP, then suffix sums
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i h = *reinterpret_cast<const v4i *>(s_hist + 4 * lane_id);
-        const int mine = h.x + h.y + h.z + h.w;
-        int pre = mine;
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false);  // row_shr:1
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);  // row_shr:2
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);  // row_shr:4
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);  // row_shr:8
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-        pre += __builtin_amdgcn_update_dpp(0, pre, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-        const int total = __builtin_amdgcn_readlane(pre, 63);
-        const int suf = total - pre + mine;   // candidates in bins >= 4l
-        const int above = suf - mine;
-        auto edge_of = [&](int want) {        // lower edge (as float bits) of the bin holding the want-th best
-            const uint64_t ge = __builtin_amdgcn_ballot_w64(suf >= want);
-            if (ge == 0ull) return 0;
-            const int top = 63 - __builtin_clzll(ge);
-            int bin = 4 * lane_id;
-            if (above + h.w >= want) bin += 3;
-            else if (above + h.w + h.z >= want) bin += 2;
-            else if (above + h.w + h.z + h.y >= want) bin += 1;
-            return __builtin_amdgcn_readlane(hist_edge_bits(bin), top);
-        };
-        const int e_k = edge_of(k), e_t = edge_of(t_band);
-        if (e_t > published) published = e_t;  // stored by the next iteration's unconditional store
-        const int edge = e_k;
-        if (edge > seg.tau_bits) {
-            seg.set_tau(__builtin_bit_cast(float, edge));
-            if (lane_id == 0) atomicMax(&s_tau, edge);
-        }
     };
 
+    if (wave < nstream)
     walk_panel<VEC, PF>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
         bool pj[VEC];
         uint64_t mk[VEC];
@@ -401,17 +408,13 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                 seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
             }
         }
-    }, iter_begin, iter_end);
-
-    if (NMS_MODE && gslot) {  // publish this band's t-th best (all its candidates are counted by now)
-        __syncthreads();
-        if (wave == 0) {
-            fetched = true;
-            iter_end(0);
-            if (lane_id == 0 && published > 0)
-                __hip_atomic_store(gslot + band, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    }, NoHook(), iter_begin);  // threshold refresh at the END of each PF-row iteration (see walk_panel)
+    if (gslot && lane_id == 0 && wave < nstream) atomicAdd(s_done, 1);
+    if ((hmode & 8) && hist_all && lane_id == 0 && wave < nstream) {  // debug: pushes / final threshold / waves, kept in the unused tail of the slot region
+        int *dbg = hist_all + (size_t)(total / nbands) * kHistBins - 16;
+        atomicAdd(dbg + 0, seg.npush); atomicMax(dbg + 1, seg.tau_bits); atomicAdd(dbg + 2, 1); atomicAdd(dbg + 3, seg.tau_bits > 1 ? 1 : 0);
     }
+
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
     if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_slot[wave] = (int)((seg.cur - smem) / cap); }
@@ -588,14 +591,15 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const long total = planes * p.nbands;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
-    const dim3 block(64 * p.nwaves);
-    const size_t lds = (size_t)p.nwaves * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
+    const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
+    const dim3 block(64 * (p.nwaves + (helper & 1)));
+    const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
     if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded);
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);

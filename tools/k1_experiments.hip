@@ -36,6 +36,46 @@ stream_only_kernel(const float *__restrict__ in, float *__restrict__ sink, int H
     if (acc == -1.f) sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// raw read ceilings: contiguous float4 per lane, UNROLL loads in flight per lane
+template <int UNROLL, int AUX>
+__global__ void __launch_bounds__(256)
+read_sum_kernel(const float *__restrict__ in, float *__restrict__ sink, size_t n4)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)0x7fffffff, 0x00020000);
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        v4f v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const float *p = in + (i + u * stride) * 4;
+            if (AUX == 0) v[u] = *reinterpret_cast<const v4f *>(p);
+            else v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == -1.f) sink[threadIdx.x] = acc;
+}
+
+template <int UNROLL, int AUX>
+float run_read(const std::vector<float *> &bufs, size_t n, void *ws, int iters, int blocks)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float sum = 0;
+    for (int it = -2; it < iters; ++it) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((read_sum_kernel<UNROLL, AUX>), dim3(blocks), dim3(256), 0, 0, bufs[(it + 2) % bufs.size()], (float *)ws, n / 4);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (it >= 0) sum += ms;
+    }
+    return sum / iters * 1e3f;
+}
+
 template <int PF>
 float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int k, int rows, void *ws, int iters, int mode)
 {
@@ -54,11 +94,11 @@ float run_band(const std::vector<float *> &bufs, long planes, int H, int W, int 
         if (mode == 1)
             hipLaunchKernelGGL((stream_only_kernel<PF>), dim3(padded), dim3(64 * nwaves), 0, 0, in, (float *)ws, H, W, rows, nbands, panel, (int)total, padded);
         else if (mode == 3)
-            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 2>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 2>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded, 0);
         else if (mode == 2)
-            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 1>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF, 1>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded, 0);
         else
-            hipLaunchKernelGGL((band_topk_kernel<4, true, PF>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded);
+            hipLaunchKernelGGL((band_topk_kernel<4, true, PF>), dim3(padded), dim3(64 * nwaves), (size_t)nwaves * 2 * 128 * 8 + 2048, 0, in, keys, cnts, (int *)nullptr, (const uint64_t *)keys, 1ull, H, W, k, 128, rows, nbands, panel, (int)total, padded, 0);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -84,6 +124,11 @@ int main(int argc, char **argv)
         printf("input: %s\n", argv[1]);
     }
     const double gb = n * 4 / 1e9;
+    for (int blocks : {1024, 2048, 4096, 8192}) {
+        float t1 = run_read<4, 0>(bufs, n, ws, 20, blocks), t2 = run_read<8, 0>(bufs, n, ws, 20, blocks), t3 = run_read<4, 1>(bufs, n, ws, 20, blocks);
+        printf("read_sum blocks=%5d  unroll4 %.1f us %.2f TB/s | unroll8 %.1f us %.2f TB/s | unroll4 nt %.1f us %.2f TB/s\n", blocks,
+               t1, gb / t1 * 1e3, t2, gb / t2 * 1e3, t3, gb / t3 * 1e3);
+    }
     printf("%-12s %5s %3s %9s %8s\n", "kernel", "rows", "pf", "us", "TB/s");
     const char *names[] = {"band_topk", "stream_only", "masks_only", "ideal_tau"};
     const int rows_list[] = {32, 40, 80};
