@@ -153,6 +153,9 @@ def main():
     fixed = [[([None, m[0]], [[], []], [[], []]), ([None, m[1]], [[], []], [[], []])] for m in maps]
     dec_ms = timed(lambda i: proc.limb_group.group_device(proc.generate_limbs(fixed[i % n_rot], flip_test=a.flip)), 20)
     bb_ms = timed(lambda i: engine.forward_raw(images[i % n_rot]), 10)
+    proc.fused_upsample = True   # K1-fused: bicubic inside the NMS kernel, no hi-res tensor (same results)
+    dec_fused_ms = timed(lambda i: proc.limb_group.group_device(proc.generate_limbs(fixed[i % n_rot], flip_test=a.flip)), 20)
+    proc.fused_upsample = False
 
     # K1 on HBM-cold inputs: rotate hi-res heatmap batches whose total exceeds the 256 MiB Infinity Cache
     hr = [decoder.factory.upsample4(m[0][:a.batch], 'bicubic') for m in maps]
@@ -182,6 +185,7 @@ def main():
                        'per_gpu_batch': a.batch, 'parallelism': f'batch-sharded x{world}, no collectives',
                        'decoder_input': 'head outputs + synthetic GT-like maps'},
             'decoder_ms_per_img': round(dec_ms / a.batch, 4),
+            'decoder_ms_per_img_fused_upsample': round(dec_fused_ms / a.batch, 4),
             'backbone_ms_per_batch': round(bb_ms, 3),
             'backbone_tflops': round(nb * FLOP_PER_IMAGE * (a.size * a.size) / (640 * 640) / (bb_ms * 1e-3) / 1e12, 1),
             'poses_last_batch': [int(len(x)) for x in poses],

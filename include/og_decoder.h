@@ -75,6 +75,15 @@ int og_topk_channel_f32(const float *scores, long planes, int H, int W, int k, f
 int og_nms_topk_f32(const float *hmps, long planes, int H, int W, int k, float *out_scores,
                     int64_t *out_inds, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- a5+a8 fused: joint_dets(F.interpolate(hmps, x4, 'bicubic'), k)  decoder/factory.py:74-75 + heatmap.py:52-59 ----
+ * hmps_lr (planes,h,w) = stride-4 head output.  The (planes,4h,4w) hi-res heatmap is never
+ * materialised: every band computes its hi-res rows on the fly (same rounding as
+ * og_upsample_bicubic4_f32) and feeds them to the same NMS / top-k machinery.  Outputs, tie rule
+ * and workspace exactly as og_nms_topk_f32 on the upsampled tensor (indices are hi-res flat
+ * indices): workspace og_topk_workspace_bytes(planes, 4h, 4w, k). */
+int og_upsample_nms_topk_f32(const float *hmps_lr, long planes, int h, int w, int k, float *out_scores,
+                             int64_t *out_inds, void *workspace, size_t workspace_bytes, void *stream);
+
 size_t og_topk_workspace_bytes(long planes, int H, int W, int k);
 
 /* ---- a9+a10: LimbsCollect.generate_limbs  decoder/collect.py:62-236 (+ _channel_dets :246-254) ----

@@ -40,6 +40,7 @@
 //     * rank-counting loops must read LDS wide (4 x ds_read_b128 per step, og_count_greater).
 #include <math.h>
 
+#include "bicubic.h"
 #include "og_common.h"
 
 namespace {
@@ -146,6 +147,76 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
     }
 }
 
+// Fused source: the hi-res rows are not read from memory but produced on the fly from the stride-4
+// head output (x4 bicubic, bit-identical to K1a): a lane owns one SOURCE column (= 4 hi-res columns),
+// keeps the x-pass results of 5 source rows in registers and emits 4 hi-res rows per source row.  The
+// +-2 source-column neighbours and the +-1 hi-res neighbours all come from DPP wave shifts, so a
+// panel has 58 interior lanes (3 halo lanes each side).  Rows/columns outside the image are 0.0
+// (F.pad), everything downstream is the same emit() as the streaming walker.
+//   lr: low-res plane (h x w); the band covers hi-res rows [r0, r1), r0 % 4 == 0.
+template <int PF, class Emit, class End = NoHook>
+__device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, int h, int w, const TileGeom &g, int q,
+                                                 Emit &&emit, End &&iter_end = NoHook())
+{
+    const int H = 4 * h;
+    const int qc = min(max(q, 0), w - 1);       // index clamp == torch's tap clamp
+    const bool in_img = q >= 0 && q < w;        // lanes outside the image produce the zero padding
+    float wt[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wt[r][j] = og_cubic_w[r][j];
+    auto src = [&](int row) { return lr[(size_t)min(max(row, 0), h - 1) * w + qc]; };
+    auto hires = [&](const OgRow4 &t0, const OgRow4 &t1, const OgRow4 &t2, const OgRow4 &t3, int phase, int Y) {
+        Px<4> o;
+        const bool ok = in_img && Y >= 0 && Y < H;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = og_cubic_chain(t0.p[x], t1.p[x], t2.p[x], t3.p[x], wt[phase]);
+            o.c[x] = ok ? v : 0.f;
+        }
+        return o;
+    };
+    const int p0 = g.r0 >> 2, p1 = g.r1 >> 2;   // source rows of the band (r0, r1 are multiples of 4)
+    // x-pass of source rows p0-2 .. p0+1: enough for hi-res row r0-1 (= phase 3 of source row p0-1)
+    OgRow4 xa = og_cubic_xpass(src(p0 - 2), wt), xb = og_cubic_xpass(src(p0 - 1), wt), xc = og_cubic_xpass(src(p0), wt),
+           xe = og_cubic_xpass(src(p0 + 1), wt);
+    Px<4> hm_a = hmax3<4>(hires(xa, xb, xc, xe, 3, g.r0 - 1));
+    OgRow4 xf = og_cubic_xpass(src(p0 + 2), wt);   // window of p0 complete: rows p0-2 .. p0+2
+    Px<4> v_b = hires(xa, xb, xc, xe, 0, g.r0);
+    Px<4> hm_b = hmax3<4>(v_b);
+    float pre[PF];                                  // prefetched source values of rows p+3 .. p+2+PF
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pre[u] = src(p0 + 3 + u);
+    for (int p = p0; p < p1; ++p) {
+#pragma unroll
+        for (int ph = 1; ph <= 4; ++ph) {          // produce hi-res row 4p+ph, emit row 4p+ph-1
+            Px<4> v_c;
+            if (ph == 1) v_c = hires(xa, xb, xc, xe, 1, 4 * p + 1);
+            else if (ph == 2) v_c = hires(xb, xc, xe, xf, 2, 4 * p + 2);
+            else if (ph == 3) v_c = hires(xb, xc, xe, xf, 3, 4 * p + 3);
+            else {                                  // first row of source row p+1: shift the window, x-pass of row p+3
+                const float nxt = pre[0];
+#pragma unroll
+                for (int u = 0; u + 1 < PF; ++u) pre[u] = pre[u + 1];
+                pre[PF - 1] = src(p + 3 + PF);
+                xa = xb; xb = xc; xc = xe; xe = xf;
+                xf = og_cubic_xpass(nxt, wt);
+                v_c = hires(xa, xb, xc, xe, 0, 4 * p + 4);
+            }
+            const Px<4> hm_c = hmax3<4>(v_c);
+            Px<4> m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m.c[j] = og_max3(hm_a.c[j], hm_b.c[j], hm_c.c[j]);
+            emit(4 * p + ph - 1, v_b, m);
+            hm_a = hm_b;
+            hm_b = hm_c;
+            v_b = v_c;
+        }
+        iter_end(p);
+    }
+}
+
 __device__ __forceinline__ TileGeom make_geom(int H, int W, int rows, int band, int panel_strips, int vec)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -249,8 +320,10 @@ struct WaveSeg {
     }
 };
 
-// ABL (tuning harness only): 0 = product; 1 = compute the admission masks but never push
-template <int VEC, bool NMS_MODE, int PF, int ABL = 0>
+// ABL (tuning harness only): 0 = product; 1 = compute the admission masks but never push.
+// FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
+// the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
+template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false>
 __global__ void __launch_bounds__(64 * kMaxWaves)
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
                  int *__restrict__ hist_all, const uint64_t *__restrict__ ws_magic, uint64_t magic,
@@ -268,8 +341,16 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     if (wid >= total) return;
     const int plane = wid / nbands, band = wid % nbands;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
-    const float *src = in + (size_t)plane * H * W;
+    TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
+    int q_lane = 0;
+    if constexpr (FUSED) {  // lanes = source columns: 58 interior + 3 halo lanes each side
+        const int lane = threadIdx.x & 63, w4 = W >> 2;
+        const int q_first = wave * panel_strips, q_cnt = min(panel_strips, w4 - q_first);
+        q_lane = q_first - 3 + lane;
+        g.col = 4 * q_lane;
+        g.interior = lane >= 3 && lane < 3 + q_cnt;
+    }
+    const float *src = in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W);
 
     WaveSeg seg;
     seg.cur = smem + (size_t)wave * 2 * cap;
@@ -370,8 +451,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         if (t > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, t));
     };
 
-    if (wave < nstream)
-    walk_panel<VEC, PF>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
+    auto emit_fn = [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
         bool pj[VEC];
         uint64_t mk[VEC];
         uint64_t any = 0;
@@ -408,7 +488,11 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                 seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
             }
         }
-    }, NoHook(), iter_begin);  // threshold refresh at the END of each PF-row iteration (see walk_panel)
+    };
+    if (wave < nstream) {  // threshold refresh at the END of each iteration (see walk_panel)
+        if constexpr (FUSED) walk_panel_fused<PF>(src, H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
+        else walk_panel<VEC, PF>(src, g, emit_fn, NoHook(), iter_begin);
+    }
     if (gslot && lane_id == 0 && wave < nstream) atomicAdd(s_done, 1);
     if ((hmode & 8) && hist_all && lane_id == 0 && wave < nstream) {  // debug: pushes / final threshold / waves, kept in the unused tail of the slot region
         int *dbg = hist_all + (size_t)(total / nbands) * kHistBins - 16;
@@ -441,7 +525,22 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 //   B) compact the keys >= L (usually just over k of them);
 //   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
-template <bool NMS_MODE>
+// one hi-res pixel of the x4 bicubic upsample of a low-res plane (same rounding as K1a)
+__device__ __forceinline__ float bicubic4_at(const float *__restrict__ lr, int h, int w, int Y, int X)
+{
+    const int qy = Y >> 2, ry = Y & 3, by = (ry < 2) ? qy - 1 : qy;
+    const int qx = X >> 2, rx = X & 3, bx = (rx < 2) ? qx - 1 : qx;
+    float rowv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *r = lr + (size_t)min(max(by - 1 + j, 0), h - 1) * w;
+        rowv[j] = og_cubic_chain(r[min(max(bx - 1, 0), w - 1)], r[min(max(bx, 0), w - 1)], r[min(max(bx + 1, 0), w - 1)],
+                                 r[min(max(bx + 2, 0), w - 1)], og_cubic_w[rx]);
+    }
+    return og_cubic_chain(rowv[0], rowv[1], rowv[2], rowv[3], og_cubic_w[ry]);
+}
+
+template <bool NMS_MODE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
                    int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
@@ -501,19 +600,20 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
     if (NMS_MODE && t < k && tid < 64) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
-        const float *p = in + (size_t)plane * H * W;
+        const float *p = in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W);
+        auto px = [&](int yy, int xx) { return FUSED ? bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
         const long hw = (long)H * W;
         for (long base = 0; base < hw && t < k; base += 64) {
             const long i = base + lane;
             bool zero = false;
             if (i < hw) {
                 const int y = (int)(i / W), x = (int)(i % W);
-                const float v = p[i];
+                const float v = px(y, x);
                 float m = (y == 0 || x == 0 || y == H - 1 || x == W - 1) ? 0.f : -INFINITY;
                 for (int dy = -1; dy <= 1; ++dy)
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int yy = y + dy, xx = x + dx;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, p[(size_t)yy * W + xx]);
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, px(yy, xx));
                     }
                 zero = !(v == m && v != 0.f);
             }
@@ -569,7 +669,7 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     return true;
 }
 
-template <bool NMS_MODE>
+template <bool NMS_MODE, bool FUSED = false>
 int run_topk(const float *in, long planes, int H, int W, int k, float *out_scores, int64_t *out_inds,
              void *workspace, size_t workspace_bytes, hipStream_t stream, const char *name)
 {
@@ -581,6 +681,13 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     Plan p;
     OG_REQUIRE(make_plan(planes, H, W, k, (uintptr_t)in % 16 == 0, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d",
                name, W, k);
+    if (FUSED) {  // lanes are source columns (58 interior per wave); bands must start on a source row
+        const int w4 = W / 4;
+        p.nwaves = (w4 + 57) / 58;
+        OG_REQUIRE(p.nwaves < kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide", name, W);
+        p.panel_strips = (w4 + p.nwaves - 1) / p.nwaves;
+        OG_REQUIRE(p.rows % 4 == 0 || p.nbands == 1, OG_EUNSUPPORTED, "%s: rows per band must be a multiple of 4", name);
+    }
     OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
     uint64_t *keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
@@ -594,7 +701,11 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
     const dim3 block(64 * (p.nwaves + (helper & 1)));
     const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
-    if (p.vec == 4)
+    if (FUSED)
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
+                           cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded,
+                           helper);
+    else if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
                            hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
     else
@@ -603,7 +714,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
-    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
+    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
                        magic, p.magic, in, H, W, k, p.nbands, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
@@ -624,6 +735,15 @@ OG_API int og_nms_topk_f32(const float *hmps, long planes, int H, int W, int k, 
 {
     return run_topk<true>(hmps, planes, H, W, k, out_scores, out_inds, workspace, workspace_bytes,
                           (hipStream_t)stream, "og_nms_topk_f32");
+}
+
+OG_API int og_upsample_nms_topk_f32(const float *hmps_lr, long planes, int h, int w, int k, float *out_scores,
+                                    int64_t *out_inds, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_upsample_nms_topk_f32";
+    OG_REQUIRE(h > 0 && w > 0 && h < (1 << 14) && w < (1 << 14), OG_EINVAL, "%s: bad shape", name);
+    return run_topk<true, true>(hmps_lr, planes, 4 * h, 4 * w, k, out_scores, out_inds, workspace, workspace_bytes,
+                                (hipStream_t)stream, name);
 }
 
 OG_API int og_topk_channel_f32(const float *scores, long planes, int H, int W, int k, float *out_scores,

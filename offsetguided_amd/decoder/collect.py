@@ -5,7 +5,7 @@ import torch
 
 from .. import _lib
 from ..config.coco_data import COCO_KEYPOINTS, COCO_PERSON_SKELETON
-from .heatmap import nms_topk_raw
+from .heatmap import _topk_raw, nms_topk_raw
 
 LOG = logging.getLogger(__name__)
 
@@ -64,17 +64,29 @@ class LimbsCollect(object):
             'spatial resolution should be equal'
         return self._collect(hmps_hr, offs_lr, off_is_lowres=True)
 
-    def _collect(self, hmps_hr, offs, off_is_lowres):
+    def generate_limbs_fused(self, hmps_lr, offs_lr):
+        """Same limbs as generate_limbs(F.interpolate(hmps_lr, x4, 'bicubic'), [], F.interpolate(offs_lr, x4,
+        'bilinear'), []) with NEITHER hi-res tensor built: K1-fused upsamples inside the NMS kernel."""
+        assert hmps_lr.shape[-2:] == offs_lr.shape[-2:], 'spatial resolution should be equal'
+        return self._collect(hmps_lr, offs_lr, off_is_lowres=True, hm_is_lowres=True)
+
+    def _collect(self, hmps_hr, offs, off_is_lowres, hm_is_lowres=False):
         hmps_hr = _lib.require_device(hmps_hr, 'hmps_hr')
         offs = _lib.require_device(offs, 'offs')
         n, c, h, w = hmps_hr.shape
+        if hm_is_lowres:
+            h, w = 4 * h, 4 * w
         n_limbs = len(self.skeleton)
         assert offs.shape[1] == 2 * n_limbs, 'offset channels must be 2 x number of limbs'
         dev = hmps_hr.device
         lib = _lib.load()
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
-        with _lib.stage_timer('k1_nms_topk', dev):
-            scores, inds = nms_topk_raw(hmps_hr, self.K)
+        if hm_is_lowres:
+            with _lib.stage_timer('k1f_upsample_nms_topk', dev):
+                scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)
+        else:
+            with _lib.stage_timer('k1_nms_topk', dev):
+                scores, inds = nms_topk_raw(hmps_hr, self.K)
         with _lib.stage_timer('k2_collect', dev):
             _lib.check(lib.og_collect_limbs_f32(
                 _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,

@@ -81,6 +81,10 @@ class PostProcess(torch.nn.Module):
         self.keypoints_flips = config.heatmap_hflip(keypoints)
         self.limbs_flips = config.offset_hflip(keypoints, skeleton)
         self.worker_pool = None  # grouping runs on the device; kept as an attribute for API parity
+        # False (default): K1a materialises the hi-res heatmaps and K1 streams them, the reference's
+        # structure and the HBM-roofline path.  True: K1-fused upsamples inside the NMS kernel
+        # (identical results, 16x less HBM traffic).
+        self.fused_upsample = False
         self._pinned, self._flip = {}, 0
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
                  'device-resident grouping', feat_stage, hmp_index, omp_index, inter_mode)
@@ -149,6 +153,8 @@ class PostProcess(torch.nn.Module):
         if scored_off:
             jf, jt = pack_jtypes(self.skeleton)
             offs = scored_offset(hmps.float(), offs.float(), jf, jt, kernel_size=3)
+        if self.fused_upsample and self.inter_mode == 'bicubic':
+            return self.limb_collect.generate_limbs_fused(hmps, offs)
         hmps_hr = upsample4(hmps, self.inter_mode)
         return self.limb_collect.generate_limbs_lowres(hmps_hr, offs)
 

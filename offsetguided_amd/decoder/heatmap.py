@@ -38,16 +38,25 @@ def nms_topk_raw(hmps, k):
     return _topk_raw("og_nms_topk_f32", hmps, k)
 
 
-def _topk_raw(entry, scores, K):
+def joint_dets_lowres(hmps_lr, k):
+    """joint_dets(F.interpolate(hmps_lr, scale_factor=4, mode='bicubic'), k) without ever building the
+    hi-res tensor (decoder/factory.py:74-75 + heatmap.py:52-59 in one kernel); indices refer to the
+    (4h, 4w) grid."""
+    out_s, out_i = _topk_raw("og_upsample_nms_topk_f32", hmps_lr, k, scale=4)
+    w = 4 * hmps_lr.shape[-1]
+    return out_s, out_i, torch.div(out_i, w, rounding_mode='floor'), out_i % w
+
+
+def _topk_raw(entry, scores, K, scale=1):
     scores = _lib.require_device(scores, "scores")
     lib = _lib.load()
     n, c, h, w = scores.shape
-    if K > h * w:
+    if K > h * w * scale * scale:
         raise RuntimeError("selected index k out of range")  # torch.topk's message
     dev = scores.device
     out_s = torch.empty((n, c, K), dtype=torch.float32, device=dev)
     out_i = torch.empty((n, c, K), dtype=torch.int64, device=dev)
-    nbytes = lib.og_topk_workspace_bytes(n * c, h, w, K)
+    nbytes = lib.og_topk_workspace_bytes(n * c, h * scale, w * scale, K)
     ws = _lib.workspace(dev, nbytes, "topk")
     fn = getattr(lib, entry)
     _lib.check(fn(_lib.ptr(scores), n * c, h, w, K, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(ws), ws.numel(),

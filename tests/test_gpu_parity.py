@@ -125,6 +125,41 @@ def test_joint_dets_histogram_state_reuse(dev):
             assert (s2.cpu().numpy() == r2[0]).all() and (i2.cpu().numpy() == r2[1]).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 2, 7, 61), (1, 1, 160, 160), (1, 3, 20, 250), (2, 17, 64, 64)])
+@pytest.mark.parametrize("k", [1, 32, 48])
+def test_joint_dets_lowres_fused_exact(dev, shape, k):
+    """K1-fused (bicubic inside the NMS kernel) == joint_dets on the materialised upsample, bit for bit."""
+    x = synth.noise_batch(26, shape, 0.05)
+    x[..., : shape[2] // 2, :] = np.abs(x[..., : shape[2] // 2, :])       # mixed-sign and positive regions
+    if k > 2 * 4 * (shape[2] + shape[3]) - 4:
+        pytest.skip("plane border smaller than k")
+    for rep in range(2):                                                   # second call: slot-table thresholds active
+        s, i, ys, xs = decoder.joint_dets_lowres(torch.from_numpy(x).to(dev), k)
+        rs, ri, ry, rx = oracle.nms_topk(oracle.bicubic4(x), k)
+        assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+        assert (ys.cpu().numpy() == ry).all() and (xs.cpu().numpy() == rx).all()
+
+
+def test_joint_dets_lowres_degenerate(dev):
+    x = np.zeros((1, 3, 16, 20), np.float32)
+    x[0, 1] = 0.25
+    x[0, 2, 5, 7] = 1.0
+    s, i, _, _ = decoder.joint_dets_lowres(torch.from_numpy(x).to(dev), 32)
+    rs, ri, _, _ = oracle.nms_topk(oracle.bicubic4(x), 32)
+    assert (s.cpu().numpy() == rs).all() and (i.cpu().numpy() == ri).all()
+
+
+@pytest.mark.parametrize("name", PIPE_CASES)
+def test_generate_poses_fused_golden(dev, name):
+    g, hm, off = load_case(name)
+    proc = processor(int(g["batch"]))
+    proc.fused_upsample = True
+    feats = features(hm, off, dev)
+    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"])).cpu().numpy()
+    assert_limbs_match(g["limbs"], limbs, SCORE_TOL)
+    assert_poses_match(split_poses(g), proc.generate_poses(feats, flip_test=bool(g["flip"])), SCORE_TOL)
+
+
 def test_topk_errors(dev):
     z = torch.zeros(1, 1, 4, 5, device=dev)
     with pytest.raises(RuntimeError):

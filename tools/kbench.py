@@ -54,6 +54,7 @@ def main():
     res['bicubic4 (w %.0f MB)' % (nbytes / 1e6)] = (timeit(lambda i: upsample4(lr[i % a.rotate], 'bicubic'), a.iters), nbytes * (1 + 1 / 16))
     res['hmp_NMS (r+w)'] = (timeit(lambda i: decoder.hmp_NMS(hr[i % a.rotate]), a.iters), 2 * nbytes)
     res['joint_dets = NMS+topk (r)'] = (timeit(lambda i: decoder.joint_dets(hr[i % a.rotate], a.k), a.iters), nbytes)
+    res['joint_dets_lowres (K1-fused)'] = (timeit(lambda i: decoder.joint_dets_lowres(lr[i % a.rotate], a.k), a.iters), nbytes / 16)
     limbs = col.generate_limbs_lowres(hr[0], offs)
     if os.environ.get('OG_DUMP_LIMBS'):
         limbs.cpu().numpy().tofile(os.environ['OG_DUMP_LIMBS'])
