@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--flip', action='store_true', help='flip-test (BASELINE config 3): 2x images through the backbone')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--overlap', action='store_true',
+                    help='run the decoder on a second HIP stream beside the next backbone (measured: no gain, the\n'
+                         'backbone already saturates the chip, and K1 then competes with the convolutions for HBM)')
     return ap.parse_args()
 
 
@@ -118,10 +121,23 @@ def main():
     def barrier():
         sharding.barrier(dev)
 
+    main_stream = torch.cuda.current_stream(dev)
+    dec_stream = torch.cuda.Stream(dev) if a.overlap else main_stream
+
     def run_steps(n, first=0):
+        """Backbone on the main stream; the decoder of batch i on a second stream, so it overlaps the
+        backbone of batch i+1 (HIP streams, event-ordered; no host sync besides the pose pick-up)."""
         pending, out = None, None
         for i in range(first, first + n):
-            nxt = proc.submit(features(i), flip_test=a.flip)
+            feats = features(i)
+            if a.overlap:
+                ready = torch.cuda.Event()
+                ready.record(main_stream)
+                dec_stream.wait_event(ready)
+                for t in (feats[0][0][1], feats[1][0][1]):
+                    t.record_stream(dec_stream)
+            with torch.cuda.stream(dec_stream):
+                nxt = proc.submit(feats, flip_test=a.flip)
             if pending is not None:
                 out = pending.result()
             pending = nxt
