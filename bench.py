@@ -181,8 +181,8 @@ def main():
     cold = _lib.profile_stop()
 
     if rank == 0:
-        k1 = float(np.mean(stage_us['k1_nms_topk'])) + float(np.mean(stage_us['k2_collect']))
-        k1_cold = float(np.mean(cold['k1_nms_topk'][3:])) + float(np.mean(cold['k2_collect'][3:]))
+        k1 = float(np.mean(stage_us['k1_generate_limbs']))
+        k1_cold = float(np.mean(cold['k1_generate_limbs'][3:]))
         k1_bytes = a.batch * K1_BYTES_PER_IMAGE * (a.size * a.size) / (640 * 640)
         achieved = k1_bytes / (k1 * 1e-6) / 1e9
         traffic = None

@@ -133,18 +133,23 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
             const Px<VEC> v_c = q[u];
             q[u] = load_row(r + u + 1 + PF);
             const Px<VEC> hm_c = hmax3<VEC>(v_c);  // all lanes take part in the DPP shifts
-            if (r + u < g.r1) {
-                Px<VEC> m;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) m.c[j] = og_max3(hm_a.c[j], hm_b.c[j], hm_c.c[j]);
-                emit(r + u, v_b, m);
-            }
+            if (r + u < g.r1) emit(r + u, v_b, hm_a, hm_b, hm_c);  // centre row + horizontal maxima of rows r-1, r, r+1
             hm_a = hm_b;
             hm_b = hm_c;
             v_b = v_c;
         }
         iter_end(r);
     }
+}
+
+// vertical 3-max of the horizontal maxima = 3x3 maximum (zero padding included)
+template <int VEC>
+__device__ __forceinline__ Px<VEC> vmax3(const Px<VEC> &a, const Px<VEC> &b, const Px<VEC> &c)
+{
+    Px<VEC> m;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m.c[j] = og_max3(a.c[j], b.c[j], c.c[j]);
+    return m;
 }
 
 // Fused source: the hi-res rows are not read from memory but produced on the fly from the stride-4
@@ -205,10 +210,7 @@ __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, i
                 v_c = hires(xa, xb, xc, xe, 0, 4 * p + 4);
             }
             const Px<4> hm_c = hmax3<4>(v_c);
-            Px<4> m;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m.c[j] = og_max3(hm_a.c[j], hm_b.c[j], hm_c.c[j]);
-            emit(4 * p + ph - 1, v_b, m);
+            emit(4 * p + ph - 1, v_b, hm_a, hm_b, hm_c);
             hm_a = hm_b;
             hm_b = hm_c;
             v_b = v_c;
@@ -250,7 +252,8 @@ nms_map_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int
     const TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
     const float *src = in + (size_t)plane * H * W;
     float *dst = out + (size_t)plane * H * W;
-    walk_panel<VEC, kPrefetch>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
+    walk_panel<VEC, kPrefetch>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &ha, const Px<VEC> &hb, const Px<VEC> &hc) {
+        const Px<VEC> m = vmax3<VEC>(ha, hb, hc);
         if (!g.interior) return;
         float o[VEC];
 #pragma unroll
@@ -274,6 +277,11 @@ struct WaveSeg {
     // strictly positive), plain mode compares floats
     int tau_bits;
     float tau_f;
+    // the same threshold as seen by this lane: halo / idle lanes carry "never" so that the hot loop
+    // needs no separate lane mask (kept in registers, refreshed only when tau changes)
+    bool emits;
+    int lane_tau_bits;
+    float lane_tau_f;
     int *hist;            // plane histogram (global) or nullptr
     int npush = 0;        // debug statistics (OG_K1_DEBUG)
 
@@ -281,6 +289,8 @@ struct WaveSeg {
     {
         tau_f = t;
         tau_bits = __builtin_bit_cast(int, t);
+        lane_tau_bits = emits ? tau_bits : 0x7fffffff;
+        lane_tau_f = emits ? t : INFINITY;
     }
 
     // Keep the k largest keys, sorted descending, in cur[0..min(cnt,k)).
@@ -357,7 +367,8 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     seg.alt = seg.cur + cap;
     seg.cap = cap;
     seg.cnt = 0;
-    if (NMS_MODE) { seg.tau_bits = 1; seg.tau_f = 0.f; }  // bits >= 1  <=>  v > +0
+    seg.emits = g.interior;  // (VEC == 1: every interior lane is inside the image as well)
+    if (NMS_MODE) seg.set_tau(__builtin_bit_cast(float, 1));  // bits >= 1  <=>  v > +0
     else seg.set_tau(-INFINITY);
     if (ABL == 2) seg.set_tau(0.035f);  // harness: what a perfect plane-wide threshold would buy
     // Plane-wide admission threshold, no atomics on global memory and NO vector-memory operation in
@@ -451,41 +462,30 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         if (t > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, t));
     };
 
-    auto emit_fn = [&](int row, const Px<VEC> &v, const Px<VEC> &m) {
-        bool pj[VEC];
-        uint64_t mk[VEC];
+    auto emit_fn = [&](int row, const Px<VEC> &v, const Px<VEC> &ha, const Px<VEC> &hb, const Px<VEC> &hc) {
+        // Threshold first: a pixel below tau can never be admitted, so the vertical maxima, the equality
+        // tests and the masks are only evaluated for wave-rows that hold a pixel >= tau (the horizontal
+        // maxima stay incremental: recomputing all three rows on demand measured slower).  Fewer
+        // instructions per row keep the kernel HBM-bound when the chip clocks down behind the backbone.
         uint64_t any = 0;
-        const bool emits = g.interior;  // (VEC == 1: every interior lane is inside the image as well)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (NMS_MODE) {
-                const int lane_tau = emits ? seg.tau_bits : 0x7fffffff;
-                pj[j] = (__builtin_bit_cast(int, v.c[j]) >= lane_tau) && (v.c[j] == m.c[j]);
-            } else {
-                const float lane_tau = emits ? seg.tau_f : INFINITY;
-                pj[j] = v.c[j] >= lane_tau;
-            }
-            mk[j] = __builtin_amdgcn_ballot_w64(pj[j]);
-            any |= mk[j];
-        }
+        for (int j = 0; j < VEC; ++j)
+            any |= __builtin_amdgcn_ballot_w64(NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits)
+                                                        : (v.c[j] >= seg.lane_tau_f));
         if (ABL == 1) {
             seg.cnt += (int)(any >> 63);  // keep the masks alive
             return;
         }
         if (any != 0ull) {
+            Px<VEC> m;
+            if (NMS_MODE) m = vmax3<VEC>(ha, hb, hc);
             const uint32_t base = (uint32_t)row * (uint32_t)W + (uint32_t)g.col;
-            const int tau_in = seg.tau_bits;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                if (mk[j] == 0ull) continue;
-                bool p = pj[j];
-                uint64_t mj = mk[j];
-                if (seg.tau_bits != tau_in) {  // an earlier component's compaction raised tau: re-test
-                    p = p && (NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.tau_bits) : (v.c[j] >= seg.tau_f));
-                    mj = __builtin_amdgcn_ballot_w64(p);
-                    if (mj == 0ull) continue;
-                }
-                seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
+            for (int j = 0; j < VEC; ++j) {  // tau may rise between components (compaction): test per component
+                const bool p = NMS_MODE ? ((__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits) && (v.c[j] == m.c[j]))
+                                        : (v.c[j] >= seg.lane_tau_f);
+                const uint64_t mj = __builtin_amdgcn_ballot_w64(p);
+                if (mj != 0ull) seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
             }
         }
     };

@@ -12,6 +12,8 @@
 //
 // Bilinear (offsets): the decode path never materialises it (K2 samples at the peaks); the
 // kernel exists for API parity and uses the same fma order as torch-CPU.
+#include <stdlib.h>
+
 #include "og_common.h"
 
 namespace {
@@ -39,7 +41,7 @@ struct Row4 {
 
 __global__ void __launch_bounds__(64 * kCubicMaxWaves)
 bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, int w, int rows, int nbands,
-                int panel_cols, int total, int padded)
+                int panel_cols, int total, int padded, int store_policy)
 {
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
@@ -87,8 +89,10 @@ bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, i
                 op[3 * 4 + x] = cubic_chain(b.p[x], c.p[x], e.p[x], f.p[x], wx[3]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float4 *>(d + (size_t)(4 * p + r) * (4 * w) + 4 * q) = o[r];
+            for (int r = 0; r < 4; ++r) {
+                float4 *dstp = reinterpret_cast<float4 *>(d + (size_t)(4 * p + r) * (4 * w) + 4 * q);
+                *dstp = o[r];
+            }
         }
         a = b; b = c; c = e; e = f;
     }
@@ -147,8 +151,9 @@ OG_API int og_upsample_bicubic4_f32(const float *src, long planes, int h, int w,
     const long total = planes * nbands;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
+    const int store_policy = 0;
     hipLaunchKernelGGL(bicubic4_kernel, dim3(padded), dim3(64 * nwaves), 0, (hipStream_t)stream, src, dst, h, w, rows,
-                       nbands, panel_cols, (int)total, padded);
+                       nbands, panel_cols, (int)total, padded, store_policy);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -81,13 +81,12 @@ class LimbsCollect(object):
         dev = hmps_hr.device
         lib = _lib.load()
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
-        if hm_is_lowres:
-            with _lib.stage_timer('k1f_upsample_nms_topk', dev):
+        # one bracket round the whole generate_limbs boundary (K1 + K2): what bench.py prices as "K1"
+        with _lib.stage_timer('k1f_fused_limbs' if hm_is_lowres else 'k1_generate_limbs', dev):
+            if hm_is_lowres:
                 scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)
-        else:
-            with _lib.stage_timer('k1_nms_topk', dev):
+            else:
                 scores, inds = nms_topk_raw(hmps_hr, self.K)
-        with _lib.stage_timer('k2_collect', dev):
             _lib.check(lib.og_collect_limbs_f32(
                 _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,
                 _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),

@@ -30,7 +30,8 @@ stream_only_kernel(const float *__restrict__ in, float *__restrict__ sink, int H
     const int plane = wid / nbands, band = wid % nbands;
     const TileGeom g = make_geom(H, W, rows, band, panel_strips, 4);
     float acc = 0.f;
-    walk_panel<4, PF>(in + (size_t)plane * H * W, g, [&](int, const Px<4> &v, const Px<4> &m) {
+    walk_panel<4, PF>(in + (size_t)plane * H * W, g, [&](int, const Px<4> &v, const Px<4> &ha, const Px<4> &hb, const Px<4> &hc) {
+        const Px<4> m = vmax3<4>(ha, hb, hc);
         acc += (v.c[0] == m.c[0]) + (v.c[1] == m.c[1]) + (v.c[2] == m.c[2]) + (v.c[3] == m.c[3]);
     });
     if (acc == -1.f) sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;

@@ -59,6 +59,7 @@ def main():
     if os.environ.get('OG_DUMP_LIMBS'):
         limbs.cpu().numpy().tofile(os.environ['OG_DUMP_LIMBS'])
     res['generate_limbs_lowres (K1+K2)'] = (timeit(lambda i: col.generate_limbs_lowres(hr[i % a.rotate], offs), a.iters), nbytes)
+    res['K1a+K1+K2 back to back'] = (timeit(lambda i: col.generate_limbs_lowres(upsample4(lr[i % a.rotate], 'bicubic'), offs), a.iters), 2 * nbytes)
     res['group_device (K3)'] = (timeit(lambda i: grp.group_device(limbs), a.iters), 0)
     for k, ((med, mn), b) in res.items():
         print(f'{k:34s} median {med:9.1f} us  min {mn:9.1f} us  {b / med / 1e6 if b else 0:8.2f} TB/s(med)')
