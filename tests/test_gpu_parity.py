@@ -297,6 +297,21 @@ def test_generate_poses_golden(dev, name):
     assert_poses_match(split_poses(g), poses, SCORE_TOL)
 
 
+@pytest.mark.parametrize("size,batch,k,flip", [((384, 512), 3, 48, False), ((128, 640), 2, 16, True), ((512, 256), 1, 32, False)])
+def test_generate_poses_nonsquare_vs_oracle(dev, size, batch, k, flip):
+    """Non-square inputs, other batch sizes and top-k values (CLI default 48), fused and unfused, vs the oracle."""
+    H, W = size
+    hm, off = synth.synth_batch(300 + H, batch, H, W, flip=flip, n_persons=4)
+    proc = processor(batch, topk=k)
+    feats = features(hm, off, dev)
+    ref, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=k, thre_hmp=FLAGS["thre_hmp"], min_len=FLAGS["min_len"],
+                           person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"], flip=flip_tables() if flip else None)
+    for fused in (False, True):
+        proc.fused_upsample = fused
+        assert_poses_match(ref, proc.generate_poses(feats, flip_test=flip), SCORE_TOL)
+        assert_poses_match(ref, proc.submit(feats, flip_test=flip).result(), SCORE_TOL)
+
+
 def test_full_size_batch_properties(dev):
     """bs8 640x640 (BASELINE config 2): size-independent properties + oracle on the same maps."""
     hm, off = synth.synth_batch(7, 8, 640, 640)
