@@ -4,15 +4,18 @@
 // The reference ships the limbs to the host (.cpu().numpy(), decoder/factory.py:91) and runs
 // numpy in a multiprocessing.Pool; here the partial-skeleton ("subset") table lives in LDS
 // (mmax x n_kp x 6 fp32, rows addressed through an order[] indirection so deletions never move
-// data) and the limb types are processed serially -- that dependence is inherent -- while
-// each step is spread over 256 lanes:
-//   * filter / stable rank-sort / to-index de-duplication of the K candidates: lanes = candidates,
-//     compaction by ballot + popcount;
+// data).  Everything that does not depend on the table -- validity filter, stable rank sort and
+// to-index de-duplication of the K candidates of EVERY limb type -- is done up front in parallel;
+// the limb types are then processed serially (that dependence is inherent), each step spread over
+// 256 lanes:
 //   * matching: lanes = (subset row, limb column) cells; per-row results by LDS atomicMax
 //     (phase B keeps the LAST matching column: numpy last-write-wins), per-column match counts
 //     by LDS atomicAdd;
-//   * merge search: lanes = (row a, row b) pairs, 17 index compares each, last partner by
-//     LDS atomicMax.
+//   * merge search: lanes = 16x16 tiles of (row a, row b) pairs, 17 index compares each, last
+//     partner by LDS atomicMax;
+//   * new rows: slot assignment by ballot + popcount in one wave, row fill by everyone.
+// Measured on MI355X (bs8, ~25 skeletons/image): 140 us per batch = up-front 21 us, pair search
+// 32 us, final scoring/sort/copy 14 us, the rest ~2 us per limb type (cycle stamps, tools/k3_experiments).
 //
 // numpy fancy-assignment semantics are kept exactly (see oracle/og_oracle.c for the literal
 // loop form).  Per subset row they reduce to:
@@ -39,11 +42,13 @@ constexpr int kThreads = 256;
 
 #ifdef OG_K3_STAMPS
 __device__ unsigned long long g_k3_stamps[16];
-#define K3_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_k3_stamps[i] += t_ - t_prev_; t_prev_ = t_; } } while (0)
-#define K3_STAMP_INIT unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
+#define K3_STAMP_INIT unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define K3_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[i] += t_ - t_prev_; t_prev_ = t_; } while (0)
+#define K3_STAMP_DUMP do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) g_k3_stamps[i_] = acc_[i_]; } while (0)
 #else
-#define K3_STAMP(i) do { } while (0)
 #define K3_STAMP_INIT do { } while (0)
+#define K3_STAMP(i) do { } while (0)
+#define K3_STAMP_DUMP do { } while (0)
 #endif
 
 struct GroupArgs {
@@ -77,197 +82,202 @@ __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairw
     return res;
 }
 
-// GSUB / LLDS are template flags, not runtime selects: a pointer that may be LDS *or* global is a
-// generic pointer, and every access through it becomes a flat_load (several times the latency of
-// ds_read, and it ties LDS traffic to vmcnt).  With static address spaces the table is plain ds_*.
-template <bool GSUB, bool LLDS>
+// GSUB is a template flag, not a runtime select: a pointer that may be LDS *or* global is a generic
+// pointer, and every access through it becomes a flat_load (several times the latency of ds_read,
+// and it ties LDS traffic to vmcnt).  With static address spaces the table is plain ds_*.
+//
+// Phases.  The per-limb-type candidate preparation (validity filter, stable rank sort, to-index
+// de-duplication, staging of the surviving rows) does not depend on the partial-skeleton table, so
+// it is done UP FRONT for all limb types at once, spread over (limb, k, j) cells -- 4 barriers in
+// total instead of 7 per limb type.  The serial loop then only matches / applies / merges / appends:
+// 5 barriers per limb type (3 when the table is still empty).
+template <bool GSUB>
 __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_nv, s_kk, s_anyA, s_anyB, s_anyQ, s_M, s_P, s_overflow, s_kept, s_new0, s_nnew;
+    __shared__ int s_anyA, s_anyB, s_anyQ, s_M, s_P, s_overflow, s_kept, s_new0, s_nnew;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = A.K, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax;
+    const int K = A.K, L = A.L, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax, LK = L * K;
     // ---- LDS carve-up (pure pointer arithmetic: an integer round trip for alignment would turn
     // everything carved after it into generic pointers, i.e. flat_load instead of ds_read) ----
     double *r_score = reinterpret_cast<double *>(lds);        // 8-byte items first: the base is 16-byte aligned
     float *p = reinterpret_cast<float *>(r_score + mmax);
-    float *c_lim = p;            p += (size_t)K * 11;      // unique limb rows: x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
-    float *c_score = p;          p += K;                   // per candidate: score (staging for the sort)
-    int *c_i2 = (int *)p;        p += K;                   // per candidate: to-index
-    int *c_ord = (int *)p;       p += K;                   // sorted valid candidates
-    int *c_uq = (int *)p;        p += K;                   // sorted, de-duplicated
+    float *lim_all = p;          p += (size_t)LK * 11;     // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
+    float *t_score = p;          p += LK;                  // up-front pass: score of valid candidates (-inf otherwise)
+    int *t_i2 = (int *)p;        p += LK;                  //                to-index
+    int *t_rank = (int *)p;      p += LK;                  //                rank among the valid ones (stable, descending)
+    int *t_dup = (int *)p;       p += LK;                  //                a better-ranked row has the same to-index
+    int *t_urank = (int *)p;     p += LK;                  //                rank among the valid, non-duplicate ones
+    int *kk_arr = (int *)p;      p += L;                   // unique rows per limb type
     int *c_n1 = (int *)p;        p += K;                   // rows with ms==1 per column
     int *c_n2 = (int *)p;        p += K;                   // rows with ms==2 per column
-    int *c_srt = (int *)p;       p += K;                   // to-index in sorted order
-    int *c_dup = (int *)p;       p += K;                   // sorted position repeats an earlier to-index
+    int *c_newcol = (int *)p;    p += K;                   // column of the i-th new row
     int *order = (int *)p;       p += mmax;                // logical position -> physical row
-    int *r_a = (int *)p;         p += mmax;                // phase-A column per logical row / merge partner
-    int *r_b = (int *)p;         p += mmax;                // phase-B last column per logical row / deleted flag
+    int *r_a = (int *)p;         p += mmax;                // phase-A column per logical row
+    int *r_b = (int *)p;         p += mmax;                // phase-B last column per logical row
+    int *r_p = (int *)p;         p += mmax;                // last merge partner
+    int *r_d = (int *)p;         p += mmax;                // deleted by a merge / dropped by the final threshold
     float *s_vals = p;           p += kThreads * 17;       // per-thread scratch for the final mean
-    float *s_limbs = p;
-    if (LLDS) p += (size_t)A.L * K * 13;
     float *sub_lds = p;
     float *sub_glb = A.gsub + (size_t)img * mmax * rowf;
 #define sub (GSUB ? sub_glb : sub_lds)
-#define SUBP(ph, j, f) sub[((size_t)(ph) * nkp + (j)) * 6 + (f)]
-#define LIM(c, f) c_lim[(size_t)(c) * 11 + (f)]
+#define SUBP(ph, j, f) sub[((ph) * nkp + (j)) * 6 + (f)]
+#define LIM(c, f) lim_l[(c) * 11 + (f)]
 
-    if (tid == 0) { s_M = 0; s_P = 0; s_overflow = 0; }
-    __syncthreads();
-    const float *limbs_glb = A.limbs + (size_t)img * A.L * K * 13;
-    if (LLDS) {  // one coalesced pass instead of two dependent global reads per limb type
-        const int n = A.L * K * 13;
-        for (int i = tid; i < n; i += kThreads) s_limbs[i] = limbs_glb[i];
-    }
-#define limbs (LLDS ? (const float *)s_limbs : limbs_glb)
-    __syncthreads();
-
+    const float *limbs = A.limbs + (size_t)img * LK * 13;
     K3_STAMP_INIT;
-    for (int l = 0; l < A.L; ++l) {
+    // ================= up-front: every limb type at once =================
+    // U1. validity filter (:64-76)
+    for (int i = tid; i < LK; i += kThreads) {
+        const float *c = limbs + (size_t)i * 13;
+        const float lim = A.use_scale ? fmaxf(A.dist_max, c[12]) : A.dist_max;
+        const bool valid = c[8] < lim && c[0] > 0.f && c[4] > 0.f && c[3] > 0.f && c[1] > 0.f;
+        t_score[i] = valid ? c[10] : -INFINITY;
+        t_i2[i] = (int)c[7];
+        t_rank[i] = 0; t_dup[i] = 0; t_urank[i] = 0;
+    }
+    for (int i = tid; i < L; i += kThreads) kk_arr[i] = 0;
+    for (int i = tid; i < K; i += kThreads) { c_n1[i] = 0; c_n2[i] = 0; }
+    if (tid == 0) { s_M = 0; s_P = 0; s_overflow = 0; s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
+    __syncthreads();
+    // U2. stable descending rank (:232) and "a better row owns my to-index" (:233-239).  One thread per
+    // candidate, serial over the K rivals of its limb type (runtime integer divisions per (k, j) cell
+    // cost more than the loop)
+    for (int lk = tid; lk < LK; lk += kThreads) {
+        const float s = t_score[lk];
+        if (s == -INFINITY) continue;
+        const int l = lk / K, k = lk - l * K, base = l * K, my_i2 = t_i2[lk];
+        int rank = 0, dup = 0;
+        for (int j = 0; j < K; ++j) {
+            const float o = t_score[base + j];
+            const bool better = o != -INFINITY && (o > s || (o == s && j < k));
+            rank += better;
+            dup |= better && (t_i2[base + j] == my_i2);
+        }
+        t_rank[lk] = rank;
+        t_dup[lk] = dup;
+    }
+    __syncthreads();
+    // U3. position among the surviving rows
+    for (int lk = tid; lk < LK; lk += kThreads) {
+        const float s = t_score[lk];
+        if (s == -INFINITY || t_dup[lk]) continue;
+        const int l = lk / K, k = lk - l * K, base = l * K;
+        int urank = 0;
+        for (int j = 0; j < K; ++j) {
+            const float o = t_score[base + j];
+            urank += (o != -INFINITY) && !t_dup[base + j] && (o > s || (o == s && j < k));
+        }
+        t_urank[lk] = urank;
+    }
+    __syncthreads();
+    // U4. stage the surviving rows in sorted order
+    for (int i = tid; i < LK; i += kThreads) {
+        if (t_score[i] == -INFINITY || t_dup[i]) continue;
+        const int l = i / K;
+        const float *r = limbs + (size_t)i * 13;
+        float *d = lim_all + ((size_t)l * K + t_urank[i]) * 11;
+        d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[11];
+        d[4] = r[3]; d[5] = r[4]; d[6] = r[5]; d[7] = r[12];
+        d[8] = r[10]; d[9] = r[6]; d[10] = r[7];
+        atomicAdd(&kk_arr[l], 1);
+    }
+    __syncthreads();
+
+    K3_STAMP(0);
+    // ================= serial over limb types =================
+    // invariant at the top: r_a = r_b = r_p = -1, r_d = 0 for rows < M; c_n1 = c_n2 = 0; flags = 0
+    for (int l = 0; l < L; ++l) {
+        const int kk = kk_arr[l];
+        if (kk == 0) continue;  // uniform
         const int jf = A.jf[l], jt = A.jt[l];
-        const float *cn = limbs + (size_t)l * K * 13;
-        // ---- 1. validity filter (:64-76) + staging ----
-        if (tid == 0) { s_nv = 0; s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
-        __syncthreads();
-        for (int k = tid; k < K; k += kThreads) {
-            const float *c = cn + (size_t)k * 13;
-            const float lim = A.use_scale ? fmaxf(A.dist_max, c[12]) : A.dist_max;
-            const bool valid = c[8] < lim && c[0] > 0.f && c[4] > 0.f && c[3] > 0.f && c[1] > 0.f;
-            c_score[k] = valid ? c[10] : -INFINITY;
-            c_i2[k] = (int)c[7];
-            if (valid) atomicAdd(&s_nv, 1);
-        }
-        __syncthreads();
-        K3_STAMP(0);
-        const int nv = s_nv;
-        if (nv == 0) continue;  // uniform
-        // ---- 2. stable sort by score descending (:232): rank by counting over (k, j) cells ----
-        for (int k = tid; k < K; k += kThreads) c_ord[k] = 0;   // reused as the rank accumulator
-        __syncthreads();
-        for (int cell = tid; cell < K * K; cell += kThreads) {
-            const int k = cell / K, j = cell - k * K;
-            const float s = c_score[k], o = c_score[j];
-            if (s != -INFINITY && o != -INFINITY && (o > s || (o == s && j < k))) atomicAdd(&c_ord[k], 1);
-        }
-        __syncthreads();
-        int my_rank = -1;
-        if (tid < K && c_score[tid] != -INFINITY) my_rank = c_ord[tid];
-        __syncthreads();
-        if (my_rank >= 0) { c_ord[my_rank] = tid; c_srt[my_rank] = c_i2[tid]; }
-        __syncthreads();
-        // ---- 3. keep the first occurrence of every to-index (:233-239): (p, q<p) cells, then wave-0 compaction ----
-        for (int p0 = tid; p0 < nv; p0 += kThreads) c_dup[p0] = 0;
-        __syncthreads();
-        for (int cell = tid; cell < nv * nv; cell += kThreads) {
-            const int pp = cell / nv, q = cell - pp * nv;
-            if (q < pp && c_srt[q] == c_srt[pp]) c_dup[pp] = 1;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            int kk = 0;
-            for (int p0 = 0; p0 < nv; p0 += 64) {
-                const int pp = p0 + lane;
-                const bool keep = pp < nv && !c_dup[pp];
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
-                if (keep) c_uq[kk + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c_ord[pp];
-                kk += __builtin_popcountll(mask);
+        const float *lim_l = lim_all + (size_t)l * K * 11;
+        const int m0 = s_M;
+        bool anyA = false, anyB = false;
+        if (m0 > 0) {
+            // ---- match against the subset table (:87-135): lanes = (row, column) cells ----
+            const int csh = 32 - __builtin_clz(max(kk - 1, 1) | 1);   // columns padded to 2^csh
+            for (int cell = tid; cell < (m0 << csh); cell += kThreads) {
+                const int m = cell >> csh, c = cell & ((1 << csh) - 1);
+                if (c >= kk) continue;
+                const int ph = order[m];
+                const int idf = (int)SUBP(ph, jf, 5), idt = (int)SUBP(ph, jt, 5);
+                const float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4), sc = LIM(c, 8);
+                const int ms = (idf == (int)LIM(c, 9)) + (idt == (int)LIM(c, 10));
+                const bool rep = sc > lst || sc > lsf;
+                if (ms == 2) { atomicAdd(&c_n2[c], 1); if (rep) { r_a[m] = c; s_anyA = 1; } }
+                if (ms == 1) { atomicAdd(&c_n1[c], 1); if (rep) { atomicMax(&r_b[m], c); s_anyB = 1; } }
             }
-            if (lane == 0) s_kk = kk;
+            __syncthreads();
+            K3_STAMP(1);
+            for (int m = tid; m < m0; m += kThreads) {
+                const int cA = r_a[m], cB = r_b[m];
+                if (cA < 0 && cB < 0) continue;
+                const int ph = order[m];
+                float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4);
+                if (cA >= 0) { lsf = fmaxf(LIM(cA, 8), lsf); lst = fmaxf(LIM(cA, 8), lst); }
+                if (cB >= 0) {
+                    SUBP(ph, jf, 5) = LIM(cB, 9); SUBP(ph, jt, 5) = LIM(cB, 10);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) { SUBP(ph, jf, f) = LIM(cB, f); SUBP(ph, jt, f) = LIM(cB, 4 + f); }
+                    lsf = fmaxf(LIM(cB, 8), lsf); lst = fmaxf(LIM(cB, 8), lst);
+                }
+                SUBP(ph, jf, 4) = lsf; SUBP(ph, jt, 4) = lst;
+            }
+            __syncthreads();
+            K3_STAMP(2);
+            anyA = s_anyA != 0;
+            anyB = s_anyB != 0;
+            // ---- merge rows sharing exactly two keypoints (:140-161): lanes = row pairs ----
+            if (m0 >= 2) {
+                // 16 x 16 tiles of (a, b) over the upper triangle: no index decoding, no divisions
+                const int ta_n = (m0 + 15) >> 4;
+                for (int ta = 0; ta < ta_n; ++ta)
+                    for (int tb = ta; tb < ta_n; ++tb) {
+                        const int a = (ta << 4) + (tid >> 4), b = (tb << 4) + (tid & 15);
+                        if (a < b && b < m0) {
+                            const int pa = order[a], pb = order[b];
+                            int cnt = 0;
+#pragma unroll
+                            for (int j = 0; j < 17; ++j)  // all 34 LDS reads issue back to back
+                                if (j < nkp) {
+                                    const int ia = (int)SUBP(pa, j, 5), ib = (int)SUBP(pb, j, 5);
+                                    cnt += (ia == ib && ia != -1);
+                                }
+                            if (cnt == 2) { atomicMax(&r_p[a], b); r_d[b] = 1; s_anyQ = 1; }
+                        }
+                    }
+                __syncthreads();
+                if (s_anyQ) {
+                    // a <- max(a, last partner); partners are deleted rows, which are never written
+                    for (int a = tid >> 7; a < m0; a += kThreads >> 7) {   // 128 lanes per row (rowf <= 102)
+                        const int f = tid & 127, b = r_p[a];
+                        if (f < rowf && b >= 0 && !r_d[a]) {
+                            const int ia = order[a] * rowf + f;
+                            sub[ia] = fmaxf(sub[ia], sub[order[b] * rowf + f]);
+                        }
+                    }
+                    __syncthreads();
+                    if (wave == 0) {  // np.delete keeps order: compact order[]
+                        int newM = 0;
+                        for (int mb = 0; mb < m0; mb += 64) {
+                            const int m = mb + lane;
+                            const bool live = m < m0 && !r_d[m];
+                            const int ph = live ? order[m] : 0;
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(live);
+                            __builtin_amdgcn_wave_barrier();
+                            if (live) order[newM + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = ph;
+                            newM += __builtin_popcountll(mask);
+                        }
+                        if (lane == 0) s_M = newM;
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        __syncthreads();
-        K3_STAMP(2);
-        const int kk = s_kk, m0 = s_M;
-        // stage the unique limb rows, zero the column counters and the per-row results
-        for (int c = tid; c < kk; c += kThreads) {
-            const float *r = cn + (size_t)c_uq[c] * 13;
-            LIM(c, 0) = r[0]; LIM(c, 1) = r[1]; LIM(c, 2) = r[2]; LIM(c, 3) = r[11];
-            LIM(c, 4) = r[3]; LIM(c, 5) = r[4]; LIM(c, 6) = r[5]; LIM(c, 7) = r[12];
-            LIM(c, 8) = r[10]; LIM(c, 9) = r[6]; LIM(c, 10) = r[7];
-            c_n1[c] = 0;
-            c_n2[c] = 0;
-        }
-        for (int m = tid; m < m0; m += kThreads) { r_a[m] = -1; r_b[m] = -1; }
-        __syncthreads();
         K3_STAMP(3);
-        // ---- 4. match against the subset table (:87-135): lanes = (row, column) cells ----
-        for (int cell = tid; cell < m0 * kk; cell += kThreads) {
-            const int m = cell / kk, c = cell - m * kk, ph = order[m];
-            const int idf = (int)SUBP(ph, jf, 5), idt = (int)SUBP(ph, jt, 5);
-            const float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4), sc = LIM(c, 8);
-            const int ms = (idf == (int)LIM(c, 9)) + (idt == (int)LIM(c, 10));
-            const bool rep = sc > lst || sc > lsf;
-            if (ms == 2) { atomicAdd(&c_n2[c], 1); if (rep) { r_a[m] = c; s_anyA = 1; } }
-            if (ms == 1) { atomicAdd(&c_n1[c], 1); if (rep) { atomicMax(&r_b[m], c); s_anyB = 1; } }
-        }
-        __syncthreads();
-        for (int m = tid; m < m0; m += kThreads) {
-            const int cA = r_a[m], cB = r_b[m];
-            if (cA < 0 && cB < 0) continue;
-            const int ph = order[m];
-            float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4);
-            if (cA >= 0) { lsf = fmaxf(LIM(cA, 8), lsf); lst = fmaxf(LIM(cA, 8), lst); }
-            if (cB >= 0) {
-                SUBP(ph, jf, 5) = LIM(cB, 9); SUBP(ph, jt, 5) = LIM(cB, 10);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) { SUBP(ph, jf, f) = LIM(cB, f); SUBP(ph, jt, f) = LIM(cB, 4 + f); }
-                lsf = fmaxf(LIM(cB, 8), lsf); lst = fmaxf(LIM(cB, 8), lst);
-            }
-            SUBP(ph, jf, 4) = lsf; SUBP(ph, jt, 4) = lst;
-        }
-        __syncthreads();
-        K3_STAMP(4);
-        const bool anyA = s_anyA != 0, anyB = s_anyB != 0;
-        // ---- 5. merge rows sharing exactly two keypoints (:140-161): lanes = row pairs ----
-        if (m0 >= 2) {
-            for (int m = tid; m < m0; m += kThreads) { r_a[m] = -1; r_b[m] = 0; }  // partner / deleted
-            __syncthreads();
-            const int npairs = m0 * (m0 - 1) / 2;
-            for (int pi = tid; pi < npairs; pi += kThreads) {
-                // pair index -> (a < b), row-major over the strict upper triangle
-                int a = (int)((2.f * m0 - 1.f - sqrtf((2.f * m0 - 1.f) * (2.f * m0 - 1.f) - 8.f * pi)) * 0.5f);
-                while (a > 0 && a * (2 * m0 - a - 1) / 2 > pi) --a;
-                while ((a + 1) * (2 * m0 - a - 2) / 2 <= pi) ++a;
-                const int b = a + 1 + (pi - a * (2 * m0 - a - 1) / 2);
-                const int pa = order[a], pb = order[b];
-                int cnt = 0;
-#pragma unroll
-                for (int j = 0; j < 17; ++j)  // all 34 LDS reads issue back to back
-                    if (j < nkp) {
-                        const int ia = (int)SUBP(pa, j, 5), ib = (int)SUBP(pb, j, 5);
-                        cnt += (ia == ib && ia != -1);
-                    }
-                if (cnt == 2) { atomicMax(&r_a[a], b); r_b[b] = 1; s_anyQ = 1; }
-            }
-            __syncthreads();
-            if (s_anyQ) {
-                // a <- max(a, last partner); partners are deleted rows, which are never written
-                for (int e = tid; e < m0 * rowf; e += kThreads) {
-                    const int a = e / rowf, f = e - a * rowf, b = r_a[a];
-                    if (b >= 0 && !r_b[a]) {
-                        const size_t ia = (size_t)order[a] * rowf + f;
-                        sub[ia] = fmaxf(sub[ia], sub[(size_t)order[b] * rowf + f]);
-                    }
-                }
-                __syncthreads();
-                if (wave == 0) {  // np.delete keeps order: compact order[]
-                    int newM = 0;
-                    for (int mb = 0; mb < m0; mb += 64) {
-                        const int m = mb + lane;
-                        const bool live = m < m0 && !r_b[m];
-                        const int ph = live ? order[m] : 0;
-                        const uint64_t mask = __builtin_amdgcn_ballot_w64(live);
-                        __builtin_amdgcn_wave_barrier();
-                        if (live) order[newM + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = ph;
-                        newM += __builtin_popcountll(mask);
-                    }
-                    if (lane == 0) s_M = newM;
-                }
-                __syncthreads();
-            }
-        }
-        K3_STAMP(5);
-        // ---- 6. unmatched limbs start new rows (:166-177): wave 0 assigns slots, everyone fills ----
+        // ---- unmatched limbs start new rows (:166-177): wave 0 assigns slots, everyone fills ----
         if (wave == 0) {
             int M = s_M, P = s_P, n_tot = 0;
             for (int c0 = 0; c0 < kk; c0 += 64) {
@@ -280,7 +290,7 @@ greedy_group_kernel(GroupArgs A)
                 const int off = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 if (fresh) {
                     order[M + off] = P + off;
-                    c_srt[n_tot + off] = c;      // column of the (n_tot+off)-th new row
+                    c_newcol[n_tot + off] = c;
                 }
                 M += n_new;
                 P += n_new;
@@ -289,26 +299,33 @@ greedy_group_kernel(GroupArgs A)
             if (lane == 0) { s_new0 = s_P; s_nnew = n_tot; s_M = M; s_P = P; }
         }
         __syncthreads();
+        K3_STAMP(4);
+        if (s_overflow) break;  // uniform
         {
-            const int n_new = s_overflow ? 0 : s_nnew, p_first = s_new0;
-            for (int e = tid; e < n_new * rowf; e += kThreads) {
-                const int r = e / rowf, jf6 = e - r * rowf, j = jf6 / 6, f = jf6 - j * 6, c = c_srt[r];
+            const int n_new = s_nnew, p_first = s_new0, M = s_M;
+            for (int r = tid >> 7; r < n_new; r += kThreads >> 7) {        // 128 lanes per new row (rowf <= 102)
+                const int jf6 = tid & 127;
+                if (jf6 >= rowf) continue;
+                const int j = jf6 / 6, f = jf6 - j * 6, c = c_newcol[r];
                 float v = -1.f;
                 if (j == jf) v = (f < 4) ? LIM(c, f) : (f == 4 ? LIM(c, 8) : LIM(c, 9));
                 else if (j == jt) v = (f < 4) ? LIM(c, 4 + f) : (f == 4 ? LIM(c, 8) : LIM(c, 10));
-                sub[(size_t)(p_first + r) * rowf + e - r * rowf] = v;
+                sub[(p_first + r) * rowf + jf6] = v;
             }
+            // re-establish the loop invariant for the next limb type
+            for (int m = tid; m < M; m += kThreads) { r_a[m] = -1; r_b[m] = -1; r_p[m] = -1; r_d[m] = 0; }
+            for (int c = tid; c < kk; c += kThreads) { c_n1[c] = 0; c_n2[c] = 0; }
+            if (tid == 0) { s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
         }
         __syncthreads();
-        K3_STAMP(6);
-        if (s_overflow) break;  // uniform
+        K3_STAMP(5);
     }
 
     if (s_overflow) {
         if (tid == 0) { A.status[img] = 1; A.counts[img] = 0; }
         return;
     }
-    // ---- _delete_sort (:187-219) ----
+    // ================= _delete_sort (:187-219) =================
     const int M = s_M;
     if (tid == 0) s_kept = 0;
     __syncthreads();
@@ -323,38 +340,39 @@ greedy_group_kernel(GroupArgs A)
         const double score = (double)np_sum17(v, n) / (double)n;  // 0/0 -> NaN -> kept, like the reference
         const bool keep = !(score < A.person_thre);
         r_score[m] = score;
-        r_b[m] = keep ? 0 : 1;
+        r_d[m] = keep ? 0 : 1;
         if (keep) atomicAdd(&s_kept, 1);
     }
     __syncthreads();
     float *out = A.poses + (size_t)img * mmax * rowf;
     for (int m = wave; m < M; m += kThreads / 64) {  // one wave per row: coalesced copy
-        if (r_b[m]) continue;
+        if (r_d[m]) continue;
         const double s = r_score[m];
         int rank = 0;
         for (int j = 0; j < M; ++j) {
             const double o = r_score[j];
-            rank += (!r_b[j]) && (o > s || (o == s && j < m));
+            rank += (!r_d[j]) && (o > s || (o == s && j < m));
         }
-        const float *src = sub + (size_t)order[m] * rowf;
+        const float *src = sub + order[m] * rowf;
         for (int f = lane; f < rowf; f += 64) {
             const float v = src[f];
             out[(size_t)rank * rowf + f] = (v == -1.f) ? 0.f : v;
         }
     }
-    K3_STAMP(7);
+    K3_STAMP(6);
+    K3_STAMP_DUMP;
     if (tid == 0) { A.counts[img] = s_kept; A.status[img] = 0; }
 #undef SUBP
 #undef LIM
 #undef sub
-#undef limbs
 }
 
 constexpr size_t kLdsLimit = 159 * 1024;  // 160 KiB per CU minus the static __shared__ words
 
-size_t staging_bytes(int K, int mmax)
+size_t staging_bytes(int L, int K, int mmax)
 {
-    return ((size_t)K * 11 + (size_t)K * 8 + (size_t)mmax * 3 + kThreads * 17) * 4 + 8 + (size_t)mmax * 8;
+    const size_t lk = (size_t)L * K;
+    return (size_t)mmax * 8 + (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64;
 }
 
 }  // namespace
@@ -375,29 +393,24 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
     OG_REQUIRE(N > 0 && L > 0 && k > 0 && mmax > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE(n_kp > 0 && n_kp <= 17, OG_EUNSUPPORTED, "%s: n_kp=%d (max 17)", name, n_kp);
     OG_REQUIRE(sort_dim >= 0 && sort_dim < 6, OG_EINVAL, "%s: sort_dim", name);
-    OG_REQUIRE(k <= kThreads, OG_EUNSUPPORTED, "%s: k=%d too large (max %d)", name, k, kThreads);
     OG_REQUIRE(mmax <= 4096, OG_EUNSUPPORTED, "%s: mmax=%d too large", name, mmax);
     GroupArgs a;
     a.limbs = limbs; a.jf = jf; a.jt = jt; a.L = L; a.K = k; a.nkp = n_kp; a.use_scale = use_scale;
     a.sort_dim = sort_dim; a.mmax = mmax; a.person_thre = person_thre; a.dist_max = dist_max;
-    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr;
-    size_t lds = staging_bytes(k, mmax);
+    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr; a.limbs_in_lds = 0;
+    size_t lds = staging_bytes(L, k, mmax);
+    OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: L*k=%d candidates (and mmax=%d) do not fit in LDS", name, L * k, mmax);
     const size_t table = (size_t)mmax * n_kp * 6 * sizeof(float);
-    const size_t limb_bytes = (size_t)L * k * 13 * sizeof(float);
-    a.limbs_in_lds = (lds + limb_bytes + table <= kLdsLimit) || (lds + limb_bytes <= kLdsLimit / 2);
-    if (a.limbs_in_lds) lds += limb_bytes;
     if (lds + table <= kLdsLimit) {
         lds += table;
     } else {
         OG_REQUIRE(workspace && workspace_bytes >= og_group_workspace_bytes(N, n_kp, mmax), OG_ENOSPC,
                    "%s: mmax=%d needs a %zu-byte workspace", name, mmax, og_group_workspace_bytes(N, n_kp, mmax));
-        OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: mmax=%d too large", name, mmax);
         a.gsub = (float *)workspace;
     }
-    void (*kern)(GroupArgs) = a.gsub ? (a.limbs_in_lds ? greedy_group_kernel<true, true> : greedy_group_kernel<true, false>)
-                                     : (a.limbs_in_lds ? greedy_group_kernel<false, true> : greedy_group_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    const int variant = (a.gsub ? 2 : 0) + (a.limbs_in_lds ? 1 : 0);
+    void (*kern)(GroupArgs) = a.gsub ? greedy_group_kernel<true> : greedy_group_kernel<false>;
+    static bool attr_set[2] = {false, false};
+    const int variant = a.gsub ? 1 : 0;
     if (!attr_set[variant]) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));

@@ -29,8 +29,8 @@ int main(int argc, char **argv)
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_k3_stamps), sizeof(z)));
         int cnt[8]; CK(hipMemcpy(cnt, meta, 32, hipMemcpyDeviceToHost));
-        printf("rc=%d %.1f us  poses %d %d %d..  stamps(100MHz ticks): filter %llu sort %llu dedupe %llu stage %llu match %llu merge %llu new %llu final %llu\n",
-               rc, ms * 1e3, cnt[0], cnt[1], cnt[2], z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        printf("rc=%d %.1f us  poses %d %d %d..  cycles: upfront %llu match %llu apply %llu pairs %llu slots %llu fill %llu final %llu\n",
+               rc, ms * 1e3, cnt[0], cnt[1], cnt[2], z[0], z[1], z[2], z[3], z[4], z[5], z[6]);
     }
     return 0;
 }
