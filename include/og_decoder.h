@@ -133,6 +133,18 @@ int og_flip_merge_f32(const float *hm, const float *off, int N, int C, int L, in
 int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream);
 int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream);
 
+/* ---- training losses, value + gradient in one pass ----
+ * og_focal_l2_loss_f32: models/losses.py:31-58 + HeatMapsLoss :174-176.  pred/gt (N,C,hw) fp32, mask_miss
+ *   (N,hw) bytes (0 = unlabelled); *sum += sum of 0.5 (s-s*)^2 |1-st|^gamma over labelled elements with finite
+ *   gt (caller zeroes *sum); grad (N,C,hw) = d sum / d pred.
+ * og_offset_l1_loss_f32: offset_instance_l1_loss :87-92 + OffsetMapsLoss :237-242.  e = |pred/ps - gt/ps| kept
+ *   if e >= margin (sqrt(e) if sqrt_re); sum_count[0] += sum, sum_count[1] += count; grad = d sum / d pred
+ *   (the caller scales by 1 / (1 + count)). */
+int og_focal_l2_loss_f32(const float *pred, const float *gt, const unsigned char *mask_miss, int N, int C, long hw,
+                         float tau, float gamma, float *sum, float *grad, void *stream);
+int og_offset_l1_loss_f32(const float *pred, const float *gt, const float *gt_ps, const unsigned char *mask_miss, int N,
+                          int C, long hw, float margin, int sqrt_re, float *sum_count, float *grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ SIGNATURES = {
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_bias_act_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "og_upsample2_add_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
+    "og_focal_l2_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _l, _f, _f, _vp, _vp, _vp]),
+    "og_offset_l1_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -69,6 +71,7 @@ def check(rc, lib=None):
 
 
 def require_device(t, name, dtype=torch.float32):
+    """Contiguous device tensor of `dtype` (a detached copy when a conversion is needed)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:

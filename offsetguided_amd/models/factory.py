@@ -1,12 +1,12 @@
 """net_cli / model_factory (reference models/factory.py:10-125), inference-relevant part.
 
-The training losses (models/losses.py) are outside this path: model_factory returns an empty
-loss list in their place, keeping the `(model, lossfuncs)` return shape evaluate.py unpacks."""
+model_factory returns `(model, lossfuncs)` like the reference; the loss objects (models/losses.py)
+are only used by the training step (train_dist.py)."""
 import logging
 import os
 
 from ..utils import boolean_string
-from . import heads, networks
+from . import heads, losses, networks
 
 LOG = logging.getLogger(__name__)
 
@@ -34,10 +34,31 @@ def net_cli(parser):
     g.add_argument('--include-background', default=False, action='store_true')
     g.add_argument('--include-jitter-offset', default=False, action='store_true')
     g.add_argument('--include-scale', default=False, action='store_true')
+    loss_cli(parser)
+
+
+def loss_cli(parser):
+    g = parser.add_argument_group('loss configuration')
+    g.add_argument('--lambdas', default=[1, 1, 100, 100, 0.01], type=float, nargs='+',
+                   help='task weights for hmp, bg_hmp, jitter_off, offset and scale losses (multiplied, not averaged)')
+    g.add_argument('--stack-weights', default=[1, 1], type=float, nargs='+', help='loss weights of the hourglass stacks')
+    g.add_argument('--hmp-loss', default='focal_l2_loss', choices=['l2_loss', 'focal_l2_loss'])
+    g.add_argument('--jitter-offset-loss', default='offset_l1_loss',
+                   choices=['offset_l1_loss', 'vector_l1_loss', 'offset_laplace_loss'])
+    g.add_argument('--offset-loss', default='offset_l1_loss',
+                   choices=['offset_l1_loss', 'vector_l1_loss', 'offset_laplace_loss', 'offset_instance_l1_loss'])
+    g.add_argument('--sqrt-re', default=False, action='store_true', help='rescale the offset loss with sqrt')
+    g.add_argument('--scale-loss', default='scale_l1_loss', choices=['scale_l1_loss'])
+    g.add_argument('--ftao', default=losses.TAU, type=float, help='fore/background threshold of the focal L2 loss')
+    g.add_argument('--fgamma', default=losses.GAMMA, type=float, help='exponent of the focal L2 scaling factor')
+    g.add_argument('--lmargin', default=losses.MARGIN, type=float, help='offset errors below this are not punished')
+    g.add_argument('--fused-losses', default=True, type=boolean_string,
+                   help='on GPU: one fused HIP kernel per loss (value + gradient) instead of torch mask/gather ops')
 
 
 def model_factory(args):
     """Build basenet + heads from the flags -> (NetworkWrapper, lossfuncs)."""
+    losses.TAU, losses.GAMMA, losses.MARGIN = args.ftao, args.fgamma, args.lmargin
     if 'hourglass' not in args.basenet:
         raise Exception(f'unknown base network: {args.basenet}')
     basenet, n_stacks, stride, max_stride, feature_dim = networks.basenet_factory(args.basenet)
@@ -57,4 +78,7 @@ def model_factory(args):
                                       args.include_background, args.include_jitter_offset, args.include_scale)
     if args.initialize_whole:
         headnets = [networks.initialize_weights(h) for h in headnets]
-    return networks.NetworkWrapper(basenet, headnets), []
+    lossfuncs = losses.lossfuncs_factory(args.headnets, n_stacks, args.stack_weights, args.hmp_loss,
+                                         args.jitter_offset_loss, args.offset_loss, args.scale_loss, args.sqrt_re,
+                                         fused=args.fused_losses)
+    return networks.NetworkWrapper(basenet, headnets), lossfuncs

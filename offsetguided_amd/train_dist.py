@@ -1,0 +1,139 @@
+"""Data-parallel training step (reference train_dist.py:108-387), MI355X-native:
+
+  apex AMP O1 + dynamic loss scaling      -> torch.autocast(bfloat16) (no scaler needed)
+  apex DistributedDataParallel            -> torch DDP over RCCL/xGMI: 25 MB gradient buckets whose
+    (delay_allreduce=True: one flat            all-reduce overlaps the rest of backward (xGMI links are
+     all-reduce after backward)                point-to-point, so overlap matters more than on NVSwitch)
+  apex SyncBatchNorm                      -> torch.nn.SyncBatchNorm (optional, --no-sync-bn)
+  apex FusedAdam                          -> torch.optim.Adam(fused=True)
+  mask/gather losses                      -> fused HIP loss kernels (models/losses.py, csrc/losses.hip)
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N -m offsetguided_amd.train_dist`);
+without COCO on disk the loop runs on synthetic encoder-style targets (GT heatmaps, patch offsets with
+inf outside the patches, instance scales, mask_miss).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import models, sharding, synth
+from .utils import AverageMeter, adjust_learning_rate
+
+
+def train_cli(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    models.net_cli(p)
+    p.add_argument('--resume', '-r', action='store_true', default=False)
+    p.add_argument('--epochs', default=100, type=int)
+    p.add_argument('--warmup', action='store_true', default=False, help='warm-up learning rate')
+    p.add_argument('--checkpoint-path', '-p', default='link2checkpoints_storage')
+    p.add_argument('--batch-size', default=8, type=int, help='per-GPU batch size')
+    p.add_argument('--square-length', default=512, type=int, help='training crop size')
+    p.add_argument('--steps-per-epoch', default=20, type=int, help='synthetic-data epoch length')
+    p.add_argument('--no-sync-bn', dest='sync_bn', action='store_false', default=True)
+    p.add_argument('--print-freq', '-f', default=10, type=int)
+    g = p.add_argument_group('optimizer configuration')
+    g.add_argument('--optimizer', type=str, default='adam', choices=['sgd', 'adam'])
+    g.add_argument('--learning-rate', type=float, default=2.5e-4, help='learning rate for world size 1')
+    g.add_argument('--momentum', default=0.9, type=float)
+    g.add_argument('--weight-decay', '--wd', default=0, type=float)
+    return p.parse_args(argv)
+
+
+def synthetic_targets(seed, batch, size, device):
+    """Encoder-style training targets (encoder/heatmap.py, encoder/offset.py conventions) for one batch:
+    annos = [(gt_hmp, gt_bghmp, gt_jomp, mask_miss), (gt_off, gt_scale, gt_ps, mask_miss)]."""
+    hm, off = synth.synth_batch(seed, batch, size, size, hm_noise=0.0, off_noise=0.0)
+    off = np.where(off == 0.0, np.inf, off).astype(np.float32)          # offsets exist in the patches only
+    h = size // 4
+    rng = synth.HashRng(seed + 17)
+    ps = rng.uniform(batch * h * h, 40.0, 300.0).reshape(batch, 1, h, h).astype(np.float32)
+    mask = torch.ones(batch, 1, h, h, dtype=torch.bool, device=device)
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return [(t(np.clip(hm, 0, 1)), None, None, mask), (t(off), None, t(ps), mask)]
+
+
+def train_step(model, criterion, optimizer, images, annos, lambdas, autocast_dtype=torch.bfloat16):
+    """One optimisation step (train_dist.py:304-342).  Returns (loss, per-head losses)."""
+    optimizer.zero_grad(set_to_none=True)
+    dev_type = 'cuda' if images.is_cuda else 'cpu'
+    with torch.autocast(dev_type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        outputs = model(images)
+    multi_losses = []
+    for out, lossfun, anno in zip(outputs, criterion, annos):
+        out32 = tuple([o.float() if isinstance(o, torch.Tensor) else o for o in part] for part in out)
+        multi_losses += list(lossfun(out32, *anno))
+    assert len(multi_losses) <= len(lambdas), 'lambdas is incomplete'
+    loss = sum(lam * l for lam, l in zip(lambdas, multi_losses))
+    if loss.item() > 1e8:  # gradient explosion: drop the batch (train_dist.py:322-325)
+        loss = loss * 0.0
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), [float(l.detach()) if torch.is_tensor(l) else float(l) for l in multi_losses]
+
+
+def main(argv=None):
+    args = train_cli(argv)
+    rank, local_rank, world = sharding.env_rank()
+    use_cuda = torch.cuda.is_available()
+    dev = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
+    if use_cuda:
+        torch.cuda.set_device(dev)
+        torch.backends.cudnn.benchmark = True
+    sharding.init(device=dev if use_cuda else None)
+    model, criterion = models.model_factory(args)
+    model = model.to(dev)
+    if use_cuda:
+        model = model.to(memory_format=torch.channels_last)
+    if world > 1 and args.sync_bn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if use_cuda else None,
+                                                          bucket_cap_mb=25, gradient_as_bucket_view=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if args.optimizer == 'adam':
+        optimizer = torch.optim.Adam(params, lr=args.learning_rate * world, weight_decay=args.weight_decay, fused=use_cuda)
+    else:
+        optimizer = torch.optim.SGD(params, lr=args.learning_rate * world, momentum=args.momentum,
+                                    weight_decay=args.weight_decay)
+    os.makedirs(args.checkpoint_path, exist_ok=True)
+    # a small rotating pool of synthetic batches per rank (generating targets on the host every step
+    # would measure numpy, not the training step)
+    pool = []
+    for i in range(4):
+        imgs = torch.randn(args.batch_size, 3, args.square_length, args.square_length, device=dev)
+        if use_cuda:
+            imgs = imgs.contiguous(memory_format=torch.channels_last)
+        pool.append((imgs, synthetic_targets(1000 * rank + i, args.batch_size, args.square_length, dev)))
+    for epoch in range(args.epochs):
+        model.train()
+        batch_time, losses, end = AverageMeter(), AverageMeter(), time.time()
+        for step in range(args.steps_per_epoch):
+            adjust_learning_rate(args.learning_rate, world, optimizer, epoch, step, args.steps_per_epoch, args.warmup)
+            images, annos = pool[step % len(pool)]
+            loss, _ = train_step(model, criterion, optimizer, images, annos, args.lambdas,
+                                 torch.bfloat16 if use_cuda else None)
+            if step % args.print_freq == 0:
+                if world > 1:  # averaged over ranks for logging only (train_dist.py:346-348, :458-466)
+                    torch.distributed.all_reduce(loss)
+                    loss = loss / world
+                if use_cuda:
+                    torch.cuda.synchronize()
+                batch_time.update((time.time() - end) / args.print_freq)
+                end = time.time()
+                losses.update(float(loss))
+                if rank == 0:
+                    print(f'epoch {epoch} [{step}/{args.steps_per_epoch}] loss {losses.val:.4f} ({losses.avg:.4f}) '
+                          f'speed {world * args.batch_size / batch_time.val:.1f} img/s')
+        if rank == 0:
+            models.save_model(os.path.join(args.checkpoint_path, f'PoseNet_{epoch}_epoch.pth'), epoch, losses.avg, model,
+                              optimizer)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,1 +1,1 @@
-from .util import AverageMeter, boolean_string  # noqa: F401
+from .util import AverageMeter, adjust_learning_rate, boolean_string  # noqa: F401

@@ -14,7 +14,7 @@ def build(seed=0):
     models.net_cli(p)
     torch.manual_seed(seed)
     model, losses = models.model_factory(p.parse_args(['--no-pretrain']))
-    assert losses == []
+    assert [type(l).__name__ for l in losses] == ['HeatMapsLoss', 'OffsetMapsLoss']
     return model
 
 
