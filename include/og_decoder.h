@@ -98,6 +98,13 @@ int og_collect_limbs_f32(const float *scores, const int64_t *inds, const float *
                          int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
                          float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
 
+/* Same with `vector_nd` offset components per limb: 2 = og_collect_limbs_f32; 4 = the `cat_flip_offs` form
+ * (decoder/factory.py:115-127 -> collect.py:62 vector_nd=4): offs (N,4L,..) from og_flip_cat_f32, match distance =
+ * the 4-D norm of (guide - to, guide' - to). */
+int og_collect_limbs_nd_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                            int vector_nd, int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L,
+                            int k, float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
+
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,
  * decoder/factory.py:91-94).
@@ -119,6 +126,12 @@ size_t og_group_workspace_bytes(int N, int n_kp, int mmax);
 int og_flip_merge_f32(const float *hm, const float *off, int N, int C, int L, int h, int w,
                       const int32_t *kp_perm, const int32_t *limb_perm, const int32_t *reserve_mask,
                       float *hm_out, float *off_out, void *stream);
+
+/* ---- a4, cat_flip_offs=True form  decoder/factory.py:115-127 ----
+ * Same inputs; off_out (N,4L,h,w): per limb [x, y, mirrored x, mirrored y] (reserve limbs repeat x, y). */
+int og_flip_cat_f32(const float *hm, const float *off, int N, int C, int L, int h, int w,
+                    const int32_t *kp_perm, const int32_t *limb_perm, const int32_t *reserve_mask,
+                    float *hm_out, float *off_out, void *stream);
 
 /* ---- backbone epilogues (bf16, channels-last / NHWC activations of the inference engine) ----
  * The convolutions stay on MIOpen; these fuse what PyTorch would launch as separate elementwise

@@ -30,9 +30,11 @@ SIGNATURES = {
     "og_upsample_nms_topk_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "og_topk_workspace_bytes": (_sz, [_l, _i, _i, _i]),
     "og_collect_limbs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
+    "og_collect_limbs_nd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "og_flip_cat_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_bias_act_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "og_upsample2_add_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
     "og_focal_l2_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _l, _f, _f, _vp, _vp, _vp]),

@@ -9,6 +9,8 @@
 //
 // fp32 arithmetic follows torch-CPU exactly where it decides an index:
 //   dist = sqrtf(fma(dy,dy, fl(dx*dx)))   (torch.norm over 2 elements)
+//   dist = sqrtf(((dx^2 + dy^2) + dx'^2) + dy'^2), no fma, for the 4-component `cat_flip_offs` form
+//          (torch's 4-element reduction rounds differently from its 2-element one)
 //   first minimum wins (torch.min tie rule on CPU)
 // exp() is the device libm (<= 1 ulp from torch's), so limb scores agree to ~1e-7 relative.
 #include <math.h>
@@ -38,6 +40,7 @@ __device__ __forceinline__ float bilinear4_at(const float *__restrict__ p, int h
     return __builtin_fmaf(a, ly0, b * ly1);
 }
 
+template <int ND>
 __global__ void __launch_bounds__(64)
 collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict__ inds,
                      const float *__restrict__ offs, int off_lowres, int C, int H, int W,
@@ -77,18 +80,19 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
         int64_t xs = xi, ys = yi;
         if (s1 < thre) { xs -= 100000; ys -= 100000; }
         const float xf = (float)xs, yf = (float)ys;
-        float ox, oy;  // offset at the ORIGINAL flat index (collect.py:143-147)
+        float o4[ND];  // offset at the ORIGINAL flat index (collect.py:143-147)
         if (off_lowres) {
             const int h4 = H / 4, w4 = W / 4;
-            const float *px = offs + ((size_t)n * 2 * L + 2 * l) * h4 * w4;
-            ox = bilinear4_at(px, h4, w4, yi, xi);
-            oy = bilinear4_at(px + (size_t)h4 * w4, h4, w4, yi, xi);
+            const float *px = offs + ((size_t)n * ND * L + ND * l) * h4 * w4;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) o4[c] = bilinear4_at(px + (size_t)c * h4 * w4, h4, w4, yi, xi);
         } else {
-            const float *px = offs + ((size_t)n * 2 * L + 2 * l) * HW;
-            ox = px[id];
-            oy = px[HW + id];
+            const float *px = offs + ((size_t)n * ND * L + ND * l) * HW;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) o4[c] = px[(size_t)c * HW + id];
         }
-        const float gx = xf + ox * resize, gy = yf + oy * resize;  // collect.py:152
+        const float gx = xf + o4[0] * resize, gy = yf + o4[1] * resize;  // collect.py:152
+        const float gx2 = ND == 4 ? xf + o4[ND - 2] * resize : 0.f, gy2 = ND == 4 ? yf + o4[ND - 1] * resize : 0.f;
         int best = 0;
         float bd = INFINITY;
         for (int m0 = 0; m0 < Kp; m0 += 4) {  // collect.py:171-177; 4 candidates per pair of wide LDS reads
@@ -97,7 +101,13 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float dx = gx - cx[j], dy = gy - cy[j];
-                const float d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+                float d;
+                if (ND == 2) {
+                    d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+                } else {
+                    const float dx2 = gx2 - cx[j], dy2 = gy2 - cy[j];
+                    d = sqrtf(((dx * dx + dy * dy) + dx2 * dx2) + dy2 * dy2);
+                }
                 if (d < bd) { bd = d; best = m0 + j; }   // strict <: first minimum wins
             }
         }
@@ -121,14 +131,24 @@ OG_API int og_collect_limbs_f32(const float *scores, const int64_t *inds, const 
                                 int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
                                 float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream)
 {
-    const char *name = "og_collect_limbs_f32";
+    return og_collect_limbs_nd_f32(scores, inds, offs, off_is_lowres, 2, N, C, H, W, jf, jt, L, k, thre_hmp, min_len,
+                                   resize_factor, limbs, stream);
+}
+
+OG_API int og_collect_limbs_nd_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                                   int vector_nd, int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L,
+                                   int k, float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream)
+{
+    const char *name = "og_collect_limbs_nd_f32";
+    OG_REQUIRE(vector_nd == 2 || vector_nd == 4, OG_EUNSUPPORTED, "%s: vector_nd must be 2 or 4", name);
     OG_REQUIRE(scores && inds && offs && jf && jt && limbs, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && L > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE(!off_is_lowres || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
     OG_REQUIRE((long)H * W < (1l << 31), OG_EINVAL, "%s: plane too large", name);
     OG_REQUIRE(k <= 2048, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
-    hipLaunchKernelGGL(collect_limbs_kernel, dim3(N * L), dim3(64), (size_t)((k + 3) & ~3) * 16, (hipStream_t)stream, scores, inds,
-                       offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs);
+    auto kern = vector_nd == 2 ? collect_limbs_kernel<2> : collect_limbs_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3(N * L), dim3(64), (size_t)((k + 3) & ~3) * 16, (hipStream_t)stream, scores, inds, offs,
+                       off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -47,37 +47,39 @@ class LimbsCollect(object):
             raise NotImplementedError('keypoint-scale head is not supported by the HIP decoder')
         if self.include_jitter_offset and isinstance(jomps_hr, torch.Tensor):
             raise NotImplementedError('jitter-offset head is not supported by the HIP decoder')
-        if vector_nd != 2:
-            raise NotImplementedError('only 2-D guiding offsets (vector_nd=2) are supported; '
-                                      'cat_flip_offs builds 4-D ones')
+        if vector_nd not in (2, 4):
+            raise NotImplementedError('guiding offsets have 2 components, or 4 with cat_flip_offs')
 
     def generate_limbs(self, hmps_hr, jomps_hr, offs_hr, scmps_hr, vector_nd=2):
         """(N,C,H,W) heatmaps + (N,2L,H,W) offsets at input resolution -> limbs (N,L,K,13)."""
         assert hmps_hr.shape[-2:] == offs_hr.shape[-2:], 'spatial resolution should be equal'
         self._check_optional_heads(jomps_hr, scmps_hr, vector_nd)
-        return self._collect(hmps_hr, offs_hr, off_is_lowres=False)
+        return self._collect(hmps_hr, offs_hr, off_is_lowres=False, vector_nd=vector_nd)
 
-    def generate_limbs_lowres(self, hmps_hr, offs_lr):
+    def generate_limbs_lowres(self, hmps_hr, offs_lr, vector_nd=2):
         """Same result as generate_limbs(hmps_hr, [], F.interpolate(offs_lr, x4, 'bilinear'), [])
         without building the hi-res offset tensor: K2 samples it at the candidate peaks."""
         assert hmps_hr.shape[-2] == 4 * offs_lr.shape[-2] and hmps_hr.shape[-1] == 4 * offs_lr.shape[-1], \
             'spatial resolution should be equal'
-        return self._collect(hmps_hr, offs_lr, off_is_lowres=True)
+        return self._collect(hmps_hr, offs_lr, off_is_lowres=True, vector_nd=vector_nd)
 
-    def generate_limbs_fused(self, hmps_lr, offs_lr):
+    def generate_limbs_fused(self, hmps_lr, offs_lr, vector_nd=2):
         """Same limbs as generate_limbs(F.interpolate(hmps_lr, x4, 'bicubic'), [], F.interpolate(offs_lr, x4,
         'bilinear'), []) with NEITHER hi-res tensor built: K1-fused upsamples inside the NMS kernel."""
         assert hmps_lr.shape[-2:] == offs_lr.shape[-2:], 'spatial resolution should be equal'
-        return self._collect(hmps_lr, offs_lr, off_is_lowres=True, hm_is_lowres=True)
+        return self._collect(hmps_lr, offs_lr, off_is_lowres=True, hm_is_lowres=True, vector_nd=vector_nd)
 
-    def _collect(self, hmps_hr, offs, off_is_lowres, hm_is_lowres=False):
+    def _collect(self, hmps_hr, offs, off_is_lowres, hm_is_lowres=False, vector_nd=2):
         hmps_hr = _lib.require_device(hmps_hr, 'hmps_hr')
         offs = _lib.require_device(offs, 'offs')
         n, c, h, w = hmps_hr.shape
         if hm_is_lowres:
             h, w = 4 * h, 4 * w
         n_limbs = len(self.skeleton)
-        assert offs.shape[1] == 2 * n_limbs, 'offset channels must be 2 x number of limbs'
+        # cat_flip_offs hands the 4-component offsets on as a (2N, 2L, h, w) view (decoder/factory.py:127);
+        # like collect.py:73 only the memory order (N, L, vector_nd, h, w) matters
+        assert offs.numel() == n * vector_nd * n_limbs * offs.shape[-2] * offs.shape[-1], \
+            'offset channels must be vector_nd x number of limbs'
         dev = hmps_hr.device
         lib = _lib.load()
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
@@ -87,8 +89,8 @@ class LimbsCollect(object):
                 scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)
             else:
                 scores, inds = nms_topk_raw(hmps_hr, self.K)
-            _lib.check(lib.og_collect_limbs_f32(
-                _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), n, c, h, w,
+            _lib.check(lib.og_collect_limbs_nd_f32(
+                _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), int(vector_nd), n, c, h, w,
                 _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
                 n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
                 _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)

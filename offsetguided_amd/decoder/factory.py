@@ -114,8 +114,6 @@ class PostProcess(torch.nn.Module):
 
     def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
         """Merge the predictions for [images, mirrored images] (decoder/factory.py:98-146)."""
-        if cat_flip_offs:
-            raise NotImplementedError('cat_flip_offs (4-D offsets, -0.5 AP in the reference) is not supported')
         if (self.include_jitter_offset and isinstance(jomps, torch.Tensor)) or \
                 (self.include_scale and isinstance(scmps, torch.Tensor)):
             raise NotImplementedError('jitter/scale heads are not supported by the HIP decoder')
@@ -127,13 +125,18 @@ class PostProcess(torch.nn.Module):
         lib = _lib.load()
         keep = [1 if l in self.limbs_flips[1] else 0 for l in range(n_limbs)]
         hm_out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
-        off_out = torch.empty((n, 2 * n_limbs, h, w), dtype=torch.float32, device=dev)
+        if cat_flip_offs:  # factory.py:115-127: keep both offsets per limb, (N, L, 4, h, w) in memory
+            vector_nd *= 2
+        off_out = torch.empty((n, vector_nd * n_limbs, h, w), dtype=torch.float32, device=dev)
+        entry = lib.og_flip_cat_f32 if cat_flip_offs else lib.og_flip_merge_f32
         with _lib.stage_timer('k0_flip_merge', dev):
-            _lib.check(lib.og_flip_merge_f32(
+            _lib.check(entry(
                 _lib.ptr(hmps), _lib.ptr(offs), n, c, n_limbs, h, w,
                 _lib.ptr(_lib.int_table(self.keypoints_flips, dev)),
                 _lib.ptr(_lib.int_table(self.limbs_flips[0], dev)),
                 _lib.ptr(_lib.int_table(keep, dev)), _lib.ptr(hm_out), _lib.ptr(off_out), _lib.stream_ptr(dev)), lib)
+        if cat_flip_offs:
+            off_out = off_out.view(n2, -1, h, w)  # the reference's (odd) shape of the same memory, factory.py:127
         return hm_out, jomps, off_out, scmps, vector_nd
 
     # ---- device-resident pieces ----------------------------------------------------------
@@ -148,15 +151,18 @@ class PostProcess(torch.nn.Module):
         if (self.include_scale and isinstance(scmps, torch.Tensor)) or \
                 (self.include_jitter_offset and isinstance(jomps, torch.Tensor)):
             raise NotImplementedError('jitter/scale heads are not supported by the HIP decoder')
+        vector_nd = 2
         if flip_test:
-            hmps, jomps, offs, scmps, _ = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, 2)
+            hmps, jomps, offs, scmps, vector_nd = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, vector_nd)
         if scored_off:
+            if vector_nd != 2:
+                raise NotImplementedError('scored_off needs 2-component offsets (the reference fails here as well)')
             jf, jt = pack_jtypes(self.skeleton)
             offs = scored_offset(hmps.float(), offs.float(), jf, jt, kernel_size=3)
         if self.fused_upsample and self.inter_mode == 'bicubic':
-            return self.limb_collect.generate_limbs_fused(hmps, offs)
+            return self.limb_collect.generate_limbs_fused(hmps, offs, vector_nd)
         hmps_hr = upsample4(hmps, self.inter_mode)
-        return self.limb_collect.generate_limbs_lowres(hmps_hr, offs)
+        return self.limb_collect.generate_limbs_lowres(hmps_hr, offs, vector_nd)
 
 
 def decoder_cli(parser):

@@ -227,10 +227,26 @@ OGO_API int ogo_nms_topk(const float *hm, long planes, int H, int W, int k, floa
 /*                 from the x4 bilinear map, factory.py:77-78) : (N,2L,H,W)   */
 /*   limbs       : (N,L,K,13) [x1,y1,v1,x2,y2,v2,ind1,ind2,dist,len,score,s1,s2] */
 /* ------------------------------------------------------------------------- */
+/* vector_nd = 2: the usual guiding offsets; 4: the `cat_flip_offs` form (decoder/factory.py:115-127), where the
+ * mirrored image's offsets ride along as components 2,3 and the match distance is the 4-D norm
+ * sqrt(((d0^2 + d1^2) + d2^2) + d3^2) -- torch's rounding for a 4-element reduction (no fma), unlike the
+ * 2-element case. */
+OGO_API void ogo_collect_limbs_nd(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                  int N, int C, int H, int W, const int *jf, const int *jt, int L, int K,
+                                  float thre, float min_len, float resize, int vector_nd, float *limbs);
+
 OGO_API void ogo_collect_limbs(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
                                int N, int C, int H, int W, const int *jf, const int *jt, int L, int K,
                                float thre, float min_len, float resize, float *limbs)
 {
+    ogo_collect_limbs_nd(scores, inds, offs, off_lowres, N, C, H, W, jf, jt, L, K, thre, min_len, resize, 2, limbs);
+}
+
+OGO_API void ogo_collect_limbs_nd(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                  int N, int C, int H, int W, const int *jf, const int *jt, int L, int K,
+                                  float thre, float min_len, float resize, int vector_nd, float *limbs)
+{
+    const int nd = vector_nd;
     const long HW = (long)H * W;
     const int h4 = H / 4, w4 = W / 4;
     float *tx = (float *)malloc(sizeof(float) * (size_t)K * 2);
@@ -251,22 +267,28 @@ OGO_API void ogo_collect_limbs(const float *scores, const int64_t *inds, const f
                 int64_t xs = xi, ys = yi;
                 if (sf[k] < thre) { xs -= 100000; ys -= 100000; }
                 float xf = (float)xs, yf = (float)ys;
-                float ox, oy; /* gather at the ORIGINAL flat index (collect.py:143-147) */
-                if (off_lowres) {
-                    const float *px = offs + ((size_t)n * 2 * L + 2 * l) * h4 * w4;
-                    ox = ogo_bilinear4_at(px, h4, w4, (int)yi, (int)xi);
-                    oy = ogo_bilinear4_at(px + (size_t)h4 * w4, h4, w4, (int)yi, (int)xi);
-                } else {
-                    const float *px = offs + ((size_t)n * 2 * L + 2 * l) * HW;
-                    ox = px[idf[k]];
-                    oy = px[HW + idf[k]];
+                float o4[4] = {0, 0, 0, 0}; /* gather at the ORIGINAL flat index (collect.py:143-147) */
+                for (int c = 0; c < nd; ++c) {
+                    if (off_lowres) {
+                        const float *px = offs + ((size_t)n * nd * L + (size_t)nd * l + c) * h4 * w4;
+                        o4[c] = ogo_bilinear4_at(px, h4, w4, (int)yi, (int)xi);
+                    } else {
+                        o4[c] = offs[((size_t)n * nd * L + (size_t)nd * l + c) * HW + idf[k]];
+                    }
                 }
-                float gx = xf + ox * resize, gy = yf + oy * resize; /* :152 */
+                float gx = xf + o4[0] * resize, gy = yf + o4[1] * resize; /* :152 */
+                float gx2 = xf + o4[2] * resize, gy2 = yf + o4[3] * resize;
                 int best = 0;
                 float bd = INFINITY;
                 for (int m = 0; m < K; ++m) { /* :171-177, first minimum */
                     float dx = gx - tx[m], dy = gy - ty[m];
-                    float d = sqrtf(fmaf(dy, dy, dx * dx));
+                    float d;
+                    if (nd == 2) {
+                        d = sqrtf(fmaf(dy, dy, dx * dx));
+                    } else {
+                        float dx2 = gx2 - tx[m], dy2 = gy2 - ty[m];
+                        d = sqrtf(((dx * dx + dy * dy) + dx2 * dx2) + dy2 * dy2);
+                    }
                     if (d < bd) { bd = d; best = m; }
                 }
                 float lx = xf - tx[best], ly = yf - ty[best];
@@ -545,6 +567,42 @@ OGO_API void ogo_flip_merge(const float *hm, const float *off, int N, int C, int
                         float fv = b[(size_t)y * w + (w - 1 - x)];
                         if (comp == 0) fv = fv * -1.0f;
                         o[(size_t)y * w + x] = keep ? a[(size_t)y * w + x] : (a[(size_t)y * w + x] + fv) / 2.f;
+                    }
+            }
+        }
+    }
+}
+
+/* PostProcess.flip_augment with cat_flip_offs=True (decoder/factory.py:115-127): the mirrored offsets are
+ * appended as components 2,3 instead of being averaged; for the `reserve` limbs (mirror = own reverse)
+ * components 2,3 are the original components 0,1.  off_out (N, L, 4, h, w). */
+OGO_API void ogo_flip_cat(const float *hm, const float *off, int N, int C, int L, int h, int w,
+                          const int *kp_perm, const int *limb_perm, const int *reserve, int n_reserve,
+                          float *hm_out, float *off_out)
+{
+    const size_t hw = (size_t)h * w;
+    for (int n = 0; n < N; ++n) {
+        for (int c = 0; c < C; ++c) {
+            const float *a = hm + ((size_t)n * C + c) * hw;
+            const float *b = hm + ((size_t)(n + N) * C + kp_perm[c]) * hw;
+            float *o = hm_out + ((size_t)n * C + c) * hw;
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) o[(size_t)y * w + x] = (a[(size_t)y * w + x] + b[(size_t)y * w + (w - 1 - x)]) / 2.f;
+        }
+        for (int l = 0; l < L; ++l) {
+            int keep = 0;
+            for (int r = 0; r < n_reserve; ++r) keep |= (reserve[r] == l);
+            for (int comp = 0; comp < 2; ++comp) {
+                const float *a = off + ((size_t)n * 2 * L + 2 * l + comp) * hw;
+                const float *b = off + ((size_t)(n + N) * 2 * L + 2 * limb_perm[l] + comp) * hw;
+                float *o0 = off_out + ((size_t)n * 4 * L + 4 * l + comp) * hw;
+                float *o1 = off_out + ((size_t)n * 4 * L + 4 * l + 2 + comp) * hw;
+                for (int y = 0; y < h; ++y)
+                    for (int x = 0; x < w; ++x) {
+                        float fv = b[(size_t)y * w + (w - 1 - x)];
+                        if (comp == 0) fv = fv * -1.0f;
+                        o0[(size_t)y * w + x] = a[(size_t)y * w + x];
+                        o1[(size_t)y * w + x] = keep ? a[(size_t)y * w + x] : fv;
                     }
             }
         }

@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "libog_oracle.so")
 
 __all__ = [
     "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
-    "greedy_group", "group_stats", "flip_merge", "decode",
+    "greedy_group", "group_stats", "flip_merge", "flip_cat", "decode",
 ]
 
 _lib = None
@@ -50,6 +50,10 @@ def lib():
         L.ogo_nms_topk.restype = C.c_int
         L.ogo_collect_limbs.argtypes = [_F, _I64, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F]
+        L.ogo_collect_limbs_nd.argtypes = [_F, _I64, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
+        L.ogo_flip_cat.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _I32, _I32, _I32, C.c_int, _F, _F]
         L.ogo_greedy_group.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_double, C.c_float,
                                        C.c_int, C.c_int, C.c_int, _F]
         L.ogo_greedy_group.restype = C.c_int
@@ -113,8 +117,9 @@ def nms_topk(hm, k):
     return os_, oi, oi // w, oi % w
 
 
-def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0):
-    """decoder/collect.py:62-236; `offs` low-res (bilinear-sampled) or hi-res (gathered)."""
+def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0, vector_nd=2):
+    """decoder/collect.py:62-236; `offs` low-res (bilinear-sampled) or hi-res (gathered); vector_nd=4 for the
+    cat_flip_offs form (offs then has 4 components per limb)."""
     scores = _f32(scores)
     inds = np.ascontiguousarray(inds, dtype=np.int64)
     offs = _f32(offs)
@@ -124,8 +129,8 @@ def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_
     jt = np.array([b for _, b in skeleton], np.int32)
     L = len(skeleton)
     limbs = np.empty((n, L, k, 13), np.float32)
-    lib().ogo_collect_limbs(scores, inds, offs, int(bool(off_lowres)), n, c, H, W, jf, jt, L, k,
-                            thre, min_len, resize, limbs)
+    lib().ogo_collect_limbs_nd(scores, inds, offs, int(bool(off_lowres)), n, c, H, W, jf, jt, L, k,
+                               thre, min_len, resize, int(vector_nd), limbs)
     return limbs
 
 
@@ -168,21 +173,39 @@ def flip_merge(hm, off, kp_perm, limb_perm, reserve):
     return ho, oo
 
 
+def flip_cat(hm, off, kp_perm, limb_perm, reserve):
+    """decoder/factory.py:115-127 (cat_flip_offs=True): off_out (N, 4L, h, w)."""
+    hm, off = _f32(hm), _f32(off)
+    n2, c, h, w = hm.shape
+    L = off.shape[1] // 2
+    n = n2 // 2
+    ho = np.empty((n, c, h, w), np.float32)
+    oo = np.empty((n, 4 * L, h, w), np.float32)
+    res = np.array(reserve, np.int32)
+    lib().ogo_flip_cat(hm, off, n, c, L, h, w, np.array(kp_perm, np.int32), np.array(limb_perm, np.int32),
+                       res if len(res) else np.zeros(1, np.int32), len(reserve), ho, oo)
+    return ho, oo
+
+
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,
-           dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False):
+           dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False, cat_flip_offs=False):
     """PostProcess.generate_poses (decoder/factory.py:52-96) on low-res head outputs.
 
     flip = (kp_perm, limb_perm, reserve) enables the flip-test merge first.
     Returns (poses list, dict of intermediates).
     """
-    if flip is not None:
+    nd = 2
+    if flip is not None and cat_flip_offs:
+        hm_lr, off_lr = flip_cat(hm_lr, off_lr, *flip)
+        nd = 4
+    elif flip is not None:
         hm_lr, off_lr = flip_merge(hm_lr, off_lr, *flip)
     hm_hr = bicubic4(hm_lr)
     n, c, H, W = hm_hr.shape
     sc, idx, _, _ = nms_topk(hm_hr, topk_k)
     if materialize_offsets:
-        limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len)
+        limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd)
     else:
-        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len)
+        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd)
     poses = [greedy_group(limbs[i], skeleton, c, person_thre, dist_max, use_scale, sort_dim) for i in range(n)]
     return poses, {"hm_hr": hm_hr, "scores": sc, "inds": idx, "limbs": limbs}

@@ -11,7 +11,7 @@ from offsetguided_amd.config.coco_data import (COCO_KEYPOINTS, COCO_PERSON_SKELE
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FLAGS = dict(topk=32, thre_hmp=0.04, person_thre=0.04, dist_max=40.0, min_len=0.5)
 PIPE_CASES = ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe256_flip_p20",
-              "pipe640", "pipe640_flip"]
+              "pipe640", "pipe640_flip", "pipe256_flipcat_p6", "pipe640_flipcat"]
 EXACT_LIMB_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12]
 EXACT_POSE_COLS = [0, 1, 2, 3, 5]
 
@@ -23,6 +23,11 @@ def sha(a):
 def flip_tables(skeleton=COCO_PERSON_SKELETON):
     perm, rev = offset_hflip(COCO_KEYPOINTS, skeleton)
     return heatmap_hflip(COCO_KEYPOINTS), perm, rev
+
+
+def is_cat(g):
+    """cat_flip_offs case (decoder/factory.py:115-127)?  Older fixtures predate the field."""
+    return bool(int(g["cat"])) if "cat" in g.files else False
 
 
 def load_case(name):

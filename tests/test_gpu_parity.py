@@ -10,7 +10,7 @@ import torch
 import oracle
 from offsetguided_amd import _lib, decoder, synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, load_case,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case,
                      split_poses)
 
 pytestmark = pytest.mark.gpu
@@ -155,9 +155,10 @@ def test_generate_poses_fused_golden(dev, name):
     proc = processor(int(g["batch"]))
     proc.fused_upsample = True
     feats = features(hm, off, dev)
-    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"])).cpu().numpy()
+    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)).cpu().numpy()
     assert_limbs_match(g["limbs"], limbs, SCORE_TOL)
-    assert_poses_match(split_poses(g), proc.generate_poses(feats, flip_test=bool(g["flip"])), SCORE_TOL)
+    assert_poses_match(split_poses(g), proc.generate_poses(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)),
+                       SCORE_TOL)
 
 
 def test_topk_errors(dev):
@@ -275,13 +276,28 @@ def test_grouping_table_overflow_retry(dev):
 
 
 # ------------------------------------------------------------------ flip merge (a4) + whole pipeline
-@pytest.mark.parametrize("name", ["pipe256_flip_p6", "pipe640_flip"])
+@pytest.mark.parametrize("name", ["pipe256_flip_p6", "pipe640_flip", "pipe256_flipcat_p6", "pipe640_flipcat"])
 def test_flip_merge_exact(dev, name):
     g, hm, off = load_case(name)
     proc = processor(int(g["batch"]))
-    mh, _, mo, _, _ = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], False, 2)
-    rh, ro = oracle.flip_merge(hm, off, *flip_tables())
-    assert (mh.cpu().numpy() == rh).all() and (mo.cpu().numpy() == ro).all()
+    cat = is_cat(g)
+    mh, _, mo, _, nd = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], cat, 2)
+    rh, ro = (oracle.flip_cat if cat else oracle.flip_merge)(hm, off, *flip_tables())
+    assert nd == (4 if cat else 2)
+    assert mo.shape == ((hm.shape[0], off.shape[1]) + hm.shape[2:] if cat else ro.shape)  # factory.py:127 view
+    assert (mh.cpu().numpy() == rh).all() and (mo.cpu().numpy().ravel() == ro.ravel()).all()
+
+
+@pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat"])
+def test_collect_limbs_4d_offsets_hires_form(dev, name):
+    """The reference's own call (collect.py:62 with vector_nd=4 on materialised hi-res offsets) == low-res sampling."""
+    g, hm, off = load_case(name)
+    proc = processor(int(g["batch"]))
+    mh, _, mo, _, nd = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], True, 2)
+    hr = decoder.factory.upsample4(mh, 'bicubic')
+    ohr = decoder.factory.upsample4(mo, 'bilinear')
+    limbs = proc.limb_collect.generate_limbs(hr, [], ohr, [], nd).cpu().numpy()
+    assert_limbs_match(g["limbs"], limbs, SCORE_TOL)
 
 
 @pytest.mark.parametrize("name", PIPE_CASES)
@@ -290,9 +306,9 @@ def test_generate_poses_golden(dev, name):
     g, hm, off = load_case(name)
     proc = processor(int(g["batch"]))
     feats = features(hm, off, dev)
-    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"])).cpu().numpy()
+    limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)).cpu().numpy()
     assert_limbs_match(g["limbs"], limbs, SCORE_TOL)
-    poses = proc.generate_poses(feats, flip_test=bool(g["flip"]))
+    poses = proc.generate_poses(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g))
     assert all(p.dtype == np.float32 for p in poses)
     assert_poses_match(split_poses(g), poses, SCORE_TOL)
 

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from offsetguided_amd import synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, load_case,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case,
                      sha, split_poses)
 
 
@@ -27,22 +27,24 @@ def test_stage_units():
 def test_pipeline_case(name):
     g, hm, off = load_case(name)
     flip = flip_tables() if int(g["flip"]) else None
+    cat = is_cat(g)
+    merge = oracle.flip_cat if cat else oracle.flip_merge
     if flip:
-        mh, mo = oracle.flip_merge(hm, off, *flip)
+        mh, mo = merge(hm, off, *flip)
         assert [sha(mh), sha(mo)] == list(g["merged_sha"])
     poses, mid = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
                                min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"],
-                               dist_max=FLAGS["dist_max"], flip=flip)
+                               dist_max=FLAGS["dist_max"], flip=flip, cat_flip_offs=cat)
     assert sha(mid["hm_hr"]) == str(g["hm_hr_sha"])
     assert (mid["scores"] == g["scores"]).all() and (mid["inds"] == g["inds"]).all()
     assert_limbs_match(g["limbs"], mid["limbs"])
     assert_poses_match(split_poses(g), poses)
     # materialised x4 bilinear offsets + plain gather give the same limbs (decoder/factory.py:77-78)
-    merged_off = oracle.flip_merge(hm, off, *flip)[1] if flip else off
+    merged_off = merge(hm, off, *flip)[1] if flip else off
     ohr = oracle.bilinear4(merged_off)
     assert sha(ohr) == str(g["off_hr_sha"])
     l2 = oracle.collect_limbs(mid["scores"], mid["inds"], ohr, False, mid["hm_hr"].shape[-2:],
-                              cd.COCO_PERSON_SKELETON, FLAGS["thre_hmp"], FLAGS["min_len"])
+                              cd.COCO_PERSON_SKELETON, FLAGS["thre_hmp"], FLAGS["min_len"], vector_nd=4 if cat else 2)
     assert (l2 == mid["limbs"]).all()
 
 

@@ -96,20 +96,20 @@ def check_poses(ref, mine, tag):
     return worst
 
 
-def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage=True):
+def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage=True, cat=False):
     hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=n_persons)
     proc = ref_processor(decoder, batch)
     # --- the reference, stage by stage (decoder/factory.py:52-96) ---
     thm, toff = torch.from_numpy(hm), torch.from_numpy(off)
     if flip:
-        m_hm, _, m_off, _, _ = proc.flip_augment(thm, [], toff, [], False, 2)
+        m_hm, _, m_off, _, nd = proc.flip_augment(thm, [], toff, [], cat, 2)
     else:
-        m_hm, m_off = thm, toff
+        m_hm, m_off, nd = thm, toff, 2
     hr = torch.nn.functional.interpolate(m_hm, scale_factor=4, mode='bicubic')
     ohr = torch.nn.functional.interpolate(m_off, scale_factor=4, mode='bilinear')
     dets = decoder.joint_dets(hr, FLAGS['topk'])
-    limbs = proc.limb_collect.generate_limbs(hr, [], ohr, [], 2).numpy()
-    poses = proc.generate_poses(features(hm, off), flip_test=flip)
+    limbs = proc.limb_collect.generate_limbs(hr, [], ohr, [], nd).numpy()
+    poses = proc.generate_poses(features(hm, off), flip_test=flip, cat_flip_offs=cat)
     proc.worker_pool.close()
     poses_serial = [proc.limb_group.group_skeletons(l) for l in limbs]
     for a, b in zip(poses, poses_serial):
@@ -120,14 +120,16 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
     if flip:
         perm, rev = offset_hflip(COCO_KEYPOINTS, COCO_PERSON_SKELETON)
         fl = (heatmap_hflip(COCO_KEYPOINTS), perm, rev)
-        o_hm, o_off = oracle.flip_merge(hm, off, *fl)
-        assert (o_hm == m_hm.numpy()).all() and (o_off == m_off.numpy()).all(), f'{name}: flip merge'
+        o_hm, o_off = (oracle.flip_cat if cat else oracle.flip_merge)(hm, off, *fl)
+        # the reference hands the cat form on as a (2N, 2L, h, w) VIEW of the same (N, 4L, h, w) memory
+        assert (o_hm == m_hm.numpy()).all() and (o_off.ravel() == m_off.numpy().ravel()).all(), f'{name}: flip merge'
+        m_off = m_off.reshape(o_off.shape)
     o_poses, o_mid = oracle.decode(hm, off, COCO_PERSON_SKELETON, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
                                    min_len=FLAGS['min_len'], person_thre=FLAGS['person_thre'],
-                                   dist_max=FLAGS['dist_max'], flip=fl)
+                                   dist_max=FLAGS['dist_max'], flip=fl, cat_flip_offs=cat)
     assert (o_mid['hm_hr'] == hr.numpy()).all(), f'{name}: bicubic not bit-exact'
     o_ohr = oracle.bilinear4(m_off.numpy())
-    assert (o_ohr == ohr.numpy()).all(), f'{name}: bilinear not bit-exact'
+    assert (o_ohr.ravel() == ohr.numpy().ravel()).all(), f'{name}: bilinear not bit-exact'
     sc, idx = dets[0].numpy(), dets[1].numpy()
     pos = sc > 0  # entries that are real peaks are fully specified; zero filler order is not
     assert (o_mid['scores'][pos] == sc[pos]).all() and (o_mid['inds'][pos] == idx[pos]).all(), f'{name}: topk'
@@ -137,7 +139,7 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
     if all_pos:
         ds = check_limbs(limbs, o_mid['limbs'], name)
         o_l2 = oracle.collect_limbs(o_mid['scores'], o_mid['inds'], o_ohr, False, hr.shape[-2:], COCO_PERSON_SKELETON,
-                                    FLAGS['thre_hmp'], FLAGS['min_len'])
+                                    FLAGS['thre_hmp'], FLAGS['min_len'], vector_nd=nd)
         assert (o_l2 == o_mid['limbs']).all(), f'{name}: low-res sampling != hi-res gather'
     dp = check_poses(poses, o_poses, name)
     # oracle grouping fed with the REFERENCE limbs must agree exactly (isolates a12)
@@ -145,7 +147,7 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
         g = oracle.greedy_group(limbs[i], COCO_PERSON_SKELETON, 17, FLAGS['person_thre'], FLAGS['dist_max'])
         assert g.shape == poses[i].shape and (g == poses[i]).all(), f'{name}: grouping on ref limbs'
 
-    out = dict(seed=seed, batch=batch, size=size, flip=int(flip), n_persons=-1 if n_persons is None else n_persons,
+    out = dict(seed=seed, batch=batch, size=size, flip=int(flip), cat=int(cat), n_persons=-1 if n_persons is None else n_persons,
                in_sha=np.array([sha(hm), sha(off)]), hm_hr_sha=np.array(sha(hr.numpy())),
                off_hr_sha=np.array(sha(ohr.numpy())), all_positive=int(all_pos),
                scores=sc, inds=idx, limbs=limbs, n_poses=np.array([len(p) for p in poses]),
@@ -272,6 +274,10 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     decoder = load_reference()
+    pipeline_case(decoder, 'pipe256_flipcat_p6', 306, 2, 256, True, 6, cat=True)
+    pipeline_case(decoder, 'pipe640_flipcat', 642, 2, 640, True, None, cat=True)
+    if '--cat-only' in sys.argv:
+        return
     stage_units()
     grouping_cases(decoder, n_fuzz=1500, n_store=60)
     for P in (0, 1, 6, 20):
