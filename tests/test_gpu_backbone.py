@@ -69,6 +69,31 @@ def test_engine_matches_eager_fp32(dev):
         assert out[0][0][0] is None and out[0][1] == [[], []]     # reference nesting, unused stack skipped
 
 
+def test_engine_matches_reference_golden(dev):
+    """The reference model's outputs on key-seeded weights (tests/golden/backbone128.npz, generated from the imported
+    reference) vs the GPU engine: fp32 engine <= 1e-3 relative, bf16 engine reported and loosely gated."""
+    import os
+    import numpy as np
+    from offsetguided_amd import synth
+    from offsetguided_amd.models.seeding import key_seeded_state
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'backbone128.npz'))
+    p = argparse.ArgumentParser()
+    models.net_cli(p)
+    model, _ = models.model_factory(p.parse_args(['--no-pretrain']))
+    model.load_state_dict(key_seeded_state(model.state_dict()))
+    model = model.to(dev).eval()
+    x = torch.from_numpy(synth.noise_batch(int(g['input_seed']), (1, 3, 128, 128))).to(dev)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 0.08)):
+        eng = models.InferenceEngine(model, 1, 128, 128, device=dev, dtype=dtype, use_graph=False)
+        out = eng(x)
+        for h, name in ((0, 'hm'), (1, 'off')):
+            ref = g[name]
+            err = np.abs(out[h][0][-1].cpu().numpy() - ref).max() / np.abs(ref).max()
+            print(f'{name} {dtype}: relative error vs reference model {err:.2e}')
+            assert err <= tol, f'{name} {dtype}: relative error {err}'
+
+
 def test_run_images_synthetic(dev):
     """evaluate.run_images end to end on synthetic batches (engine + pipelined decode + result dicts)."""
     from offsetguided_amd import evaluate

@@ -2,11 +2,15 @@
 the reference's dict layout and 'module.' prefixes, BN folding of the inference engine (fp32, no graph)."""
 import argparse
 import os
+import zlib
 
+import numpy as np
 import pytest
 import torch
 
-from offsetguided_amd import models
+from offsetguided_amd import models, synth
+from offsetguided_amd.models.seeding import key_seeded_state
+from helpers import GOLDEN
 
 
 def build(seed=0):
@@ -78,3 +82,24 @@ def test_engine_bn_folding_cpu():
         r, o = ref[h][0][-1], out[h][0][-1]
         assert (o - r).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
     assert out[0][0][0] is None and out[1][1] == [[], []]
+
+
+def test_backbone_golden_from_reference():
+    """tests/golden/backbone128.npz holds the REFERENCE model's head outputs (tools/gen_golden_backbone.py: same
+    key-seeded weights in both models, bit-identical there).  Same CPU fp32 path here; the tolerance only covers a
+    different host's conv kernels / thread count."""
+    g = np.load(os.path.join(GOLDEN, 'backbone128.npz'))
+    model = build().eval()
+    sd = model.state_dict()
+    keys = '\n'.join(f'{k} {tuple(v.shape)}' for k, v in sd.items()).encode()
+    assert len(sd) == int(g['n_keys']) and zlib.crc32(keys) == int(g['keys_crc'])     # reference names, order, shapes
+    model.load_state_dict(key_seeded_state(sd))
+    x = torch.from_numpy(synth.noise_batch(int(g['input_seed']), (1, 3, 128, 128)))
+    with torch.no_grad():
+        out = model(x)
+    for h, name in ((0, 'hm'), (1, 'off')):
+        ref = g[name]
+        err = np.abs(out[h][0][1].numpy() - ref).max() / np.abs(ref).max()
+        assert err <= 1e-5, f'{name}: relative error {err} vs the reference model'
+        s0 = out[h][0][0]
+        assert abs(s0.std().item() - g[f'{name}_s0_stats'][1]) <= 1e-4 * g[f'{name}_s0_stats'][1]
