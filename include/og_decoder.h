@@ -146,6 +146,20 @@ int og_flip_cat_f32(const float *hm, const float *off, int N, int C, int L, int 
 int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream);
 int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream);
 
+/* ---- 3x3 stride-1 pad-1 convolution with the epilogue fused, for the small inner hourglass levels ----
+ * out = act(conv3x3(x, w) + bias (+ skip)):  convolution.forward models/hourglass_104.py:26-30 / residual.forward
+ * :70-79 with BN folded.  x (N,H,W,Cin), w (Cout,3,3,Cin) [= channels_last (Cout,Cin,3,3)], skip/out (N,H,W,Cout),
+ * all bf16; bias fp32[Cout]; Cin, Cout multiples of 64; fp32 accumulation, one rounding to bf16.
+ * Split-K implicit GEMM on MFMA: meant for N*H*W of a few hundred to a few thousand pixels, where library
+ * kernels leave most CUs idle.  workspace: og_conv3x3_workspace_bytes(N*H*W, Cin, Cout), 256-byte aligned,
+ * ZERO-INITIALISED once by the caller (its first 256 bytes are read as the zero padding and never written). */
+int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
+                    int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout);
+/* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
+ * (device memory, 64 B per workgroup); NULL switches it off. */
+void og_conv3x3_debug_stamps(void *buf);
+
 /* ---- training losses, value + gradient in one pass ----
  * og_focal_l2_loss_f32: models/losses.py:31-58 + HeatMapsLoss :174-176.  pred/gt (N,C,hw) fp32, mask_miss
  *   (N,hw) bytes (0 = unlabelled); *sum += sum of 0.5 (s-s*)^2 |1-st|^gamma over labelled elements with finite

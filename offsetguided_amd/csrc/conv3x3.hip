@@ -1,0 +1,436 @@
+// Split-K implicit-GEMM 3x3 convolution (stride 1, pad 1) for the bf16 NHWC inference engine, with the
+// bias / residual-add / ReLU epilogue fused (convolution.forward models/hourglass_104.py:26-30,
+// residual.forward :70-79).
+//
+// Why: at batch 8 the inner hourglass levels (20x20, 10x10, 5x5: 70 of the 3x3 convolutions) are GEMMs with
+// only M = 3200 / 800 / 200 output pixels against K = 9*Cin = 3456..4608.  Library kernels tile M x N only, so
+// they run 32..200 workgroups with a 54..72-step serial K loop each: 23..42 us per layer for 1..8 GFLOP, i.e.
+// 2 % of the network's FLOPs in 20 % of its time.  Here the K loop is split over workgroups as well
+// (grid = M tiles x N tiles x K splits ~ one or two workgroups per CU), every workgroup streams its K slice
+// through a 3/4-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), and the fp32
+// partial tiles meet inside the same launch: the split that arrives last at a tile's ticket counter sums the
+// others' slabs into its registers and applies the epilogue (a separate reduce kernel cost 5-6 us per layer).
+//
+// GEMM view: D[cout][pixel] = sum_k Wt[cout][k] * X[pixel][k],  k = tap*Cin + ci  (tap = 3*dy+dx).
+//   "A" operand = weights, OHWI = the memory order of a channels_last (Cout,Cin,3,3) tensor: row = cout,
+//   K contiguous.  "B" operand = im2col rows gathered on the fly: row = pixel, 64 consecutive channels of one
+//   tap per K step; taps that fall outside the image (and rows past M) are sourced from a zero page.
+//   Both LDS tiles are [row][64 bf16] = 128 B per row, fragments by ds_read_b128.  With the weights as the MFMA
+//   A operand the accumulator holds 4 consecutive couts per lane (v_mfma_f32_16x16x32_bf16: D row =
+//   4*(lane>>4)+reg, col = lane&15), so partials / outputs are stored 16 B / 8 B per lane, channel-contiguous.
+// LDS swizzle: 16-B slot index ^= (row>>1)&7 -- conflict-free for ds_read_b128's lane groups
+//   ({0-3,12-15,20-27}, ...; MI355X_MICROARCH "LDS").  LDS-DMA writes lane-linear, so the permutation is applied
+//   to the per-lane SOURCE address and again to the read address (same involution).
+// Pipeline: STAGES-deep ring, one raw s_barrier per K step, counted vmcnt (never 0 in steady state): the wait
+//   that retires step s comes before the barrier, the reads after it; the stage refilled after the barrier is
+//   the one whose reads every wave finished (lgkmcnt(0)) before arriving.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "og_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kZeroPageBytes = 256;
+
+struct ConvArgs {
+    const unsigned short *x;     // (N,H,W,Cin) bf16
+    const unsigned short *w;     // (Cout,3,3,Cin) bf16
+    const float *bias;           // fp32[Cout]
+    const unsigned short *skip;  // (N,H,W,Cout) bf16 or null
+    unsigned short *out;         // (N,H,W,Cout) bf16
+    float *partial;              // [tile][ksplit][NT*MT][256 lanes] x 4 fp32 slabs (ksplit > 1)
+    int *counters;               // [tiles] arrival tickets, zero between launches
+    const unsigned short *zero;  // >= 16 B of zeros
+    int N, H, W, Cin, Cout, M;
+    int n_tiles, steps_per_split, ksplit, relu;
+    int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
+    unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
+};
+
+#define CONV_STAMP(i)                                                                                         \
+    do {                                                                                                      \
+        if (a.stamps && tid == 0)                                                                             \
+            a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+
+__device__ __forceinline__ void glds16(const void *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0()
+{
+    // vmcnt(N) lgkmcnt(0): simm16 = vmcnt[3:0] | expcnt(7)<<4 | lgkmcnt(0)<<8 | vmcnt[5:4]<<14
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+// Epilogue of one BM x BN tile: lane holds couts co..co+3 of pixel pm in acc[n][m].
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BN / 32][BM / 32], const ConvArgs &a, int m0, int n0,
+                                               int wave, int lane)
+{
+    constexpr int MT = BM / 32, NT = BN / 32;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pm = m0 + wm * (BM / 2) + m * 16 + (lane & 15);
+        if (pm >= a.M) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + co);
+            if (a.skip) {
+                const u16x4 sk = *reinterpret_cast<const u16x4 *>(a.skip + (size_t)pm * a.Cout + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += bf2f(sk[j]);
+            }
+            u16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(a.relu ? fmaxf(v[j], 0.f) : v[j]);
+            *reinterpret_cast<u16x4 *>(a.out + (size_t)pm * a.Cout + co) = o;
+        }
+    }
+}
+
+template <int BM, int BN, int STAGES>
+__global__ void __launch_bounds__(256)
+conv3x3_kernel(ConvArgs a)
+{
+    constexpr int kRowB = 128;                      // bytes per LDS tile row (64 bf16)
+    constexpr int kStage = (BM + BN) * kRowB;
+    constexpr int PX = BM / 32, PW = BN / 32;       // 16-B pieces per thread per step: pixels, weights
+    constexpr int G = PX + PW;
+    constexpr int MT = BM / 32, NT = BN / 32;       // 16-wide sub-tiles per wave (2 x 2 waves)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    CONV_STAMP(0);
+    const int m_tile = blockIdx.x / a.n_tiles, n_tile = blockIdx.x % a.n_tiles, split = blockIdx.y;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int step0 = split * a.steps_per_split;
+    const int nsteps = a.steps_per_split;
+    const int chunks = a.Cin >> 6;                  // K steps per tap
+
+    // ---- loader set-up: piece p = tid + 256*i -> tile row p/8, LDS slot p%8, source chunk slot^((row>>1)&7)
+    const unsigned short *px_ptr[PX];
+    uint32_t px_mask[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const int xw = m % a.W, t = m / a.W, y = t % a.H;
+        uint32_t mask = 0;
+        if (m < a.M) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = xw + tap % 3 - 1;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) mask |= 1u << tap;
+            }
+        }
+        px_mask[i] = mask;
+        px_ptr[i] = a.x + (size_t)(m < a.M ? m : 0) * a.Cin + c * 8;
+    }
+    const unsigned short *w_ptr[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
+        w_ptr[i] = a.w + (size_t)(n0 + r) * 9 * a.Cin + c * 8;
+    }
+    const int lds_piece = (wave * 64) * 16;  // wave-uniform; + lane*16 is implied by the DMA
+
+    auto issue = [&](int step_local, int buf) {
+        const int step = step0 + step_local;
+        const int tap = step / chunks, ci0 = (step - tap * chunks) << 6;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long shift = ((long)dy * a.W + dx) * a.Cin + ci0;
+        unsigned char *base = lds + buf * kStage + lds_piece;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const unsigned short *src = (px_mask[i] >> tap) & 1 ? px_ptr[i] + shift : a.zero;
+            glds16(src, base + i * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(w_ptr[i] + (size_t)step * 64, base + BM * kRowB + i * 4096);
+    };
+
+    // ---- compute set-up
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fk = lane >> 4;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int px_off[MT], w_off[NT], px_sw[MT], w_sw[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = wm * (BM / 2) + m * 16 + frow;
+        px_off[m] = r * kRowB;
+        px_sw[m] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = wn * (BN / 2) + n * 16 + frow;
+        w_off[n] = BM * kRowB + r * kRowB;
+        w_sw[n] = (r >> 1) & 7;
+    }
+
+    // ---- prologue: STAGES-1 steps in flight (the host guarantees nsteps >= STAGES-1)
+#pragma unroll
+    for (int j = 0; j < STAGES - 1; ++j) issue(j, j);
+    CONV_STAMP(1);
+
+    int buf = 0, nbuf = STAGES - 1;
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + STAGES - 2 < nsteps) wait_vm_lgkm0<(STAGES - 2) * G>();
+        else wait_vm_lgkm0<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s == 0) CONV_STAMP(2);
+        if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, nbuf);
+        const unsigned char *st = lds + buf * kStage;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 pf[MT], wf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                pf[m] = *reinterpret_cast<const bf16x8 *>(st + px_off[m] + (((fk + 4 * kh) ^ px_sw[m]) << 4));
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                wf[n] = *reinterpret_cast<const bf16x8 *>(st + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+    }
+
+    CONV_STAMP(3);
+    // ---- split-K meeting point: every split writes its fp32 tile as a lane-linear slab (1 KiB per wave store),
+    // the split that arrives last adds the others to its registers and runs the epilogue.  Hand-off as
+    // cdna_hip_programming.md "in-launch split-K reduction", sc1 form: write-through (sc1) slab stores ->
+    // vmcnt(0) -> barrier -> relaxed agent-scope ticket; the last arriver reads every slab with sc1 loads.
+    // (An agent-scope release fence per workgroup instead writes back the XCD's whole L2 each time: measured
+    // 3-10x slower here.)  Correct for any placement of a tile's splits over XCDs.
+    if (a.ksplit > 1 && !a.in_launch_reduce) {
+        // plain slab stores; conv_finish_kernel (next launch on the stream) sums them and runs the epilogue
+        f32x4 *slab = reinterpret_cast<f32x4 *>(a.partial) + ((size_t)blockIdx.x * a.ksplit + split) * (NT * MT * 256) + tid;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) slab[(n * MT + m) * 256] = acc[n][m];
+        return;
+    }
+    if (a.ksplit > 1) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const int tile = blockIdx.x;
+        constexpr uint32_t kSlabBytes = NT * MT * 256 * 16;
+        const __amdgpu_buffer_rsrc_t tile_slabs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char *>(a.partial) + (size_t)tile * a.ksplit * kSlabBytes, 0, (int)(a.ksplit * kSlabBytes), 0x00020000);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), tile_slabs,
+                                                       (n * MT + m) * 4096 + tid * 16, split * kSlabBytes, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(lds);
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == a.ksplit - 1;
+            if (last) __hip_atomic_store(a.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        CONV_STAMP(4);
+        if (!*flag) return;
+        // all loads of a batch are issued before the first add (one memory round trip per batch, not per slab);
+        // the own slab and slots past ksplit are read out of range, which a buffer load returns as 0
+        constexpr int kBatch = NT * MT >= 16 ? 1 : 16 / (NT * MT);
+        for (int sp0 = 0; sp0 < a.ksplit; sp0 += kBatch) {
+            f32x4 part[kBatch][NT * MT];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const int sp = sp0 + b;
+                const uint32_t soff = (sp < a.ksplit && sp != split) ? sp * kSlabBytes : a.ksplit * kSlabBytes;
+#pragma unroll
+                for (int i = 0; i < NT * MT; ++i)
+                    part[b][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tile_slabs, i * 4096 + tid * 16, soff, 16));
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[n][m] += part[b][n * MT + m];
+        }
+    }
+
+    epilogue_store<BM, BN>(acc, a, m0, n0, wave, lane);
+    CONV_STAMP(5);
+}
+
+// Second launch of the two-launch form: one workgroup per output tile sums the ksplit slabs (coalesced 16 B per
+// lane, all loads independent) and runs the epilogue with the thread mapping of the conv kernel.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+conv_finish_kernel(ConvArgs a)
+{
+    constexpr int MT = BM / 32, NT = BN / 32;
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const f32x4 *slab = reinterpret_cast<const f32x4 *>(a.partial) + (size_t)tile * a.ksplit * (NT * MT * 256) + tid;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = slab[(n * MT + m) * 256];
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+        const f32x4 *o = slab + (size_t)sp * (NT * MT * 256);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] += o[(n * MT + m) * 256];
+    }
+    epilogue_store<BM, BN>(acc, a, (tile / a.n_tiles) * BM, (tile % a.n_tiles) * BN, tid >> 6, tid & 63);
+}
+
+struct Plan {
+    int bm, bn, stages, ksplit, steps_per_split, m_tiles, n_tiles, in_launch;
+};
+
+// Tile and K split.  Measured inside the network (bs8, tools/bb_bench.py, whole-forward ms): 64-wide tiles with
+// ~6 K splits 10.82, 64/3 10.89, shape-dependent 128-wide tiles 11.15, 128/3 11.85, no split 11.82; MIOpen 11.59.
+bool make_plan(long M, int Cin, int Cout, Plan &p)
+{
+    const int steps = 9 * Cin / 64;
+    const char *e = getenv("OG_CONV_PLAN");  // "bm,ksplit,stages" override for tuning
+    int bm = 64, force_split = 0, force_stages = 0;
+    if (e) sscanf(e, "%d,%d,%d", &bm, &force_split, &force_stages);
+    if (bm != 64 && bm != 128) return false;
+    if (bm == 128 && Cout % 128 != 0) return false;
+    p.bm = p.bn = bm;
+    p.stages = bm == 128 ? 3 : 4;
+    if (force_stages == 4 || (force_stages == 3 && bm == 128) || (force_stages == 8 && bm == 64)) p.stages = force_stages;
+    p.m_tiles = (int)((M + bm - 1) / bm);
+    p.n_tiles = Cout / bm;
+    int best = 1;
+    for (int ks = 2; ks <= 6; ++ks)
+        if (steps % ks == 0 && steps / ks >= 4 && steps / ks >= p.stages - 1) best = ks;
+    if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
+    if (steps < p.stages - 1) return false;
+    p.ksplit = best;
+    p.steps_per_split = steps / best;
+    // In-launch reduction saves a launch but pays one memory round trip per slab batch in the last arriver; measured
+    // inside the network it wins for the 5x5 level only (13.3 vs 14.9 us) and loses at 20x20 (39.9 vs 34.2 us).
+    p.in_launch = M <= 512;
+    if (const char *r = getenv("OG_CONV_REDUCE")) p.in_launch = atoi(r);
+    return true;
+}
+
+// [zero page 256 B | tickets int32[kMaxTiles] | slabs], returns the total size.  The ticket area has a FIXED size:
+// layers of different shapes share one workspace, and a ticket must never sit where another layer's slabs go.
+constexpr size_t kMaxTiles = 16384;
+size_t ws_layout(const Plan &p, size_t *counters_off, size_t *slabs_off)
+{
+    const size_t tiles = (size_t)p.m_tiles * p.n_tiles;
+    const size_t c_off = kZeroPageBytes, s_off = c_off + kMaxTiles * sizeof(int);
+    if (counters_off) *counters_off = c_off;
+    if (slabs_off) *slabs_off = s_off;
+    return s_off + (p.ksplit > 1 ? tiles * p.ksplit * (size_t)p.bm * p.bn * sizeof(float) : 0);
+}
+
+unsigned long long *g_stamps = nullptr;
+
+}  // namespace
+
+// Debug aid (tools/conv_bench.py --stamps): device buffer of [workgroups][8] u64 that later launches fill with
+// s_memrealtime marks; pass NULL to switch off.  Not part of the product path.
+OG_API void og_conv3x3_debug_stamps(void *buf) { g_stamps = (unsigned long long *)buf; }
+
+OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
+{
+    Plan p;
+    if (pixels <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || !make_plan(pixels, Cin, Cout, p)) return 0;
+    return ws_layout(p, nullptr, nullptr);
+}
+
+OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,
+                           int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_conv3x3_bf16";
+    OG_REQUIRE(x && w && bias && out && workspace, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0, OG_EUNSUPPORTED,
+               "%s: channels must be multiples of 64 (got %d -> %d)", name, Cin, Cout);
+    const long M = (long)N * H * W;
+    OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 31), OG_EUNSUPPORTED, "%s: tensor too large", name);
+    OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
+    Plan p;
+    OG_REQUIRE(make_plan(M, Cin, Cout, p), OG_EUNSUPPORTED, "%s: no tile plan", name);
+    OG_REQUIRE((size_t)p.m_tiles * p.n_tiles <= kMaxTiles, OG_EUNSUPPORTED, "%s: too many tiles", name);
+    const size_t need = og_conv3x3_workspace_bytes(M, Cin, Cout);
+    OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu bytes", name, workspace_bytes, need);
+
+    ConvArgs a;
+    a.x = (const unsigned short *)x;
+    a.w = (const unsigned short *)w;
+    a.bias = bias;
+    a.skip = (const unsigned short *)skip;
+    a.out = (unsigned short *)out;
+    a.zero = (const unsigned short *)workspace;  // first 256 B: zero page (workspace is zero-initialised by the caller)
+    size_t c_off, s_off;
+    ws_layout(p, &c_off, &s_off);
+    a.counters = (int *)((char *)workspace + c_off);
+    a.partial = (float *)((char *)workspace + s_off);
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = (int)M;
+    a.stamps = g_stamps;
+    a.in_launch_reduce = p.in_launch;
+    a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
+    const dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)p.ksplit);
+    hipStream_t st = (hipStream_t)stream;
+#define CONV_LAUNCH(BM_, ST_)                                                                                   \
+    do {                                                                                                        \
+        constexpr int lds_ = ST_ * 2 * BM_ * 128;                                                               \
+        static bool attr_ = false;                                                                              \
+        if (!attr_) {                                                                                           \
+            (void)hipFuncSetAttribute((const void *)conv3x3_kernel<BM_, BM_, ST_>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
+            attr_ = true;                                                                                       \
+        }                                                                                                       \
+        hipLaunchKernelGGL((conv3x3_kernel<BM_, BM_, ST_>), grid, dim3(256), lds_, st, a);                      \
+    } while (0)
+    if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);
+    else if (p.bm == 128) CONV_LAUNCH(128, 3);
+    else if (p.stages == 8) CONV_LAUNCH(64, 8);
+    else CONV_LAUNCH(64, 4);
+#undef CONV_LAUNCH
+    if (p.ksplit > 1 && !p.in_launch) {
+        OG_LAUNCH_CHECK(name);
+        const dim3 fgrid((unsigned)(p.m_tiles * p.n_tiles));
+        if (p.bm == 128) hipLaunchKernelGGL((conv_finish_kernel<128, 128>), fgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_finish_kernel<64, 64>), fgrid, dim3(256), 0, st, a);
+    }
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

@@ -14,6 +14,8 @@ the hardware wants:
 The result keeps the reference nesting [ (hmps[S], bg[S], jo[S]), (offs[S], spreads[S], scales[S]) ]
 (models/networks.py:189-194); stacks that are not decoded hold None.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -50,6 +52,22 @@ def _epilogue(y, bias32, bias_lp, skip, relu, fused):
     return F.relu_(y) if relu else y
 
 
+# Layers with at most this many output pixels (N*H*W) run on the hand-written split-K MFMA kernel
+# (og_conv3x3_bf16, epilogue fused) instead of MIOpen + og_bias_act_bf16: the 20x20 / 10x10 / 5x5 levels at bs8.
+CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
+_conv_ws = {}
+
+
+def _conv3x3_workspace(device, nbytes):
+    """One zero-initialised scratch per device for og_conv3x3_bf16 (zero page + split-K slabs).  Layers run
+    back to back on one stream, so they share it; it only ever grows outside graph capture."""
+    buf = _conv_ws.get(device.index)
+    if buf is None or buf.numel() < nbytes:
+        assert not torch.cuda.is_current_stream_capturing(), 'conv3x3 workspace must be sized before graph capture'
+        buf = _conv_ws[device.index] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
+
 class _Conv:
     """Folded conv: weight in the engine dtype (channels-last), bias kept apart for the epilogue."""
 
@@ -60,12 +78,31 @@ class _Conv:
         self.b = b.to(dtype)
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
         self.fused = fused and w.shape[0] % 8 == 0
+        self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1)
+                       and tuple(conv.padding) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
 
     def raw(self, x):
         return F.conv2d(x, self.w, None, self.stride, self.pad)
 
     def __call__(self, x, skip=None):
+        n, c, h, w = x.shape
+        if self.hip3x3 and n * h * w <= CONV3X3_MAX_PIXELS:
+            return self._hip(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
+
+    def _hip(self, x, skip):
+        n, c, h, w = x.shape
+        cout = self.w.shape[0]
+        assert x.is_contiguous(memory_format=torch.channels_last)
+        if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+        lib = _lib.load()
+        out = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ws = _conv3x3_workspace(x.device, lib.og_conv3x3_workspace_bytes(n * h * w, c, cout))
+        _lib.check(lib.og_conv3x3_bf16(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
+                                       _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout,
+                                       int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
+        return out
 
 
 class _Residual:

@@ -44,6 +44,51 @@ def test_upsample2_add_matches_torch(dev):
     assert torch.equal(up, ref)
 
 
+@pytest.mark.parametrize("shape", [(8, 5, 5, 512, 512), (8, 10, 10, 384, 384), (2, 20, 20, 384, 384), (3, 7, 9, 64, 128),
+                                   (1, 1, 1, 128, 64), (8, 20, 20, 384, 384), (2, 33, 31, 128, 256)])
+@pytest.mark.parametrize("reduce_mode", ["0", "1"])
+def test_conv3x3_matches_torch(dev, shape, reduce_mode, monkeypatch):
+    """og_conv3x3_bf16 (split-K MFMA kernel, fused epilogue) vs an fp32 torch convolution of the same bf16 operands:
+    differences are the final bf16 rounding (2^-9 relative) plus fp32 summation order."""
+    import torch.nn.functional as F
+    monkeypatch.setenv("OG_CONV_REDUCE", reduce_mode)       # 1 = last-arriver in-launch reduction, 0 = finish kernel
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + cin)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    skip = torch.randn(n, cout, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    ws = torch.zeros(lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout), dtype=torch.uint8, device=dev)
+    for use_skip, relu in ((True, 1), (False, 0)):
+        ref = F.conv2d(x.float(), wt.float(), bias, 1, 1)
+        if use_skip:
+            ref = ref + skip.float()
+        if relu:
+            ref = F.relu(ref)
+        out = torch.full_like(skip, float('nan'))
+        for _ in range(2):                                   # second call: tickets must be back at zero
+            _lib.check(lib.og_conv3x3_bf16(_lib.ptr(x), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None,
+                                           _lib.ptr(out), n, h, w, cin, cout, relu, _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(dev)), lib)
+        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 6e-3, f'relative error {err}'
+    assert ws[:256].count_nonzero().item() == 0              # the zero page is never written
+
+
+def test_conv3x3_rejects_bad_arguments(dev):
+    lib = _lib.load()
+    x = torch.zeros(1, 64, 4, 4, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    b = torch.zeros(64, device=dev)
+    args = lambda cin, cout, wsb: (_lib.ptr(x), _lib.ptr(x), _lib.ptr(b), None, _lib.ptr(x), 1, 4, 4, cin, cout, 1,  # noqa: E731
+                                   _lib.ptr(ws), wsb, _lib.stream_ptr(dev))
+    assert lib.og_conv3x3_bf16(*args(48, 64, ws.numel())) == -4          # OG_EUNSUPPORTED: channels % 64
+    assert lib.og_conv3x3_bf16(*args(64, 64, 128)) == -2                 # OG_ENOSPC
+    assert lib.og_conv3x3_workspace_bytes(16, 48, 64) == 0
+
+
 def test_engine_matches_eager_fp32(dev):
     import bench
     p = argparse.ArgumentParser()

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""og_conv3x3_bf16 vs MIOpen conv + og_bias_act_bf16 on the hourglass's 3x3 shapes: numerics against an fp32
+torch convolution and GPU time per call (both captured in HIP graphs of `reps` calls)."""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from offsetguided_amd import _lib  # noqa: E402
+
+SHAPES = [(8, 5, 5, 512, 512), (8, 10, 10, 384, 384), (8, 20, 20, 384, 384), (8, 40, 40, 384, 384),
+          (8, 5, 5, 384, 512), (8, 40, 40, 256, 384), (8, 80, 80, 256, 256), (16, 20, 20, 384, 384), (16, 5, 5, 512, 512)]
+
+
+_flush = None
+
+
+def graph_time(fn, reps, rounds=5, cold=True):
+    """us per call of fn(l), l = 0..reps-1 (distinct weights/activations per l), captured in one graph.  cold: every
+    timed replay starts behind a 1 GiB fill, so the weights come from HBM as they do inside the network."""
+    global _flush
+    if cold and _flush is None:
+        _flush = torch.empty(1 << 30, dtype=torch.uint8, device='cuda:0')
+    for l in range(reps):
+        fn(l)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for l in range(reps):
+            fn(l)
+    g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(rounds):
+        if cold:
+            _flush.fill_(1)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e) * 1e3 / reps)
+    return sorted(times)[len(times) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--plans', default='', help='comma list of "bm:ksplit" overrides to sweep, e.g. 64:4,64:8,128:2')
+    ap.add_argument('--only', type=int, default=-1)
+    ap.add_argument('--stamps', action='store_true', help='print in-kernel timeline (us) of one cold launch per plan')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(0)
+    for si, (n, h, w, cin, cout) in enumerate(SHAPES):
+        if a.only >= 0 and si != a.only:
+            continue
+        cl = torch.channels_last
+        xs = [torch.randn(n, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(a.reps)]
+        wts = [(torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(torch.bfloat16)
+               .contiguous(memory_format=cl) for _ in range(a.reps)]
+        bias = torch.randn(cout, device=dev) * 0.1
+        skip = torch.randn(n, cout, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=cl)
+        ref = F.relu(F.conv2d(xs[-1].float(), wts[-1].float(), bias, 1, 1) + skip.float())
+        out = torch.empty_like(skip)
+        need = lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout)
+        ws = torch.zeros(max(need, 256) * 8, dtype=torch.uint8, device=dev)  # room for any split override
+
+        def ours(l=-1):
+            _lib.check(lib.og_conv3x3_bf16(_lib.ptr(xs[l]), _lib.ptr(wts[l]), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(out),
+                                           n, h, w, cin, cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+
+        def miopen(l=-1):
+            y = F.conv2d(xs[l], wts[l], None, 1, 1)
+            _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(skip), n * h * w, cout, 1,
+                                            _lib.stream_ptr(dev)), lib)
+            return y
+
+        t_ref = graph_time(miopen, a.reps)
+        gflop = 2 * n * h * w * cout * 9 * cin / 1e9
+        line = f'{n}x{h}x{w} {cin}->{cout} ({gflop:.2f} GF): miopen+epilogue {t_ref:7.1f} us'
+        for plan in [''] + [p for p in a.plans.split(',') if p]:
+            if plan:
+                os.environ['OG_CONV_PLAN'] = plan.replace(':', ',')
+            else:
+                os.environ.pop('OG_CONV_PLAN', None)
+            out.zero_()
+            try:
+                ours()
+            except Exception as ex:  # noqa: BLE001
+                line += f' | {plan or "auto"}: {str(ex)[:40]}'
+                continue
+            torch.cuda.synchronize()
+            err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            if a.stamps:
+                st = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+                _flush.fill_(1)
+                torch.cuda.synchronize()
+                lib.og_conv3x3_debug_stamps(_lib.ptr(st))
+                ours(0)
+                torch.cuda.synchronize()
+                lib.og_conv3x3_debug_stamps(None)
+                v = st.view(-1, 8).cpu().numpy()
+                v = v[v[:, 0] > 0]
+                t0 = v[:, 0].min()
+                rel = (v - t0) / 100.0
+                names = ['start', 'issued', 'first data', 'loop end', 'ticket', 'end(last)']
+                print(f'   [{plan or "auto"}] {len(v)} workgroups; us since first start (median / max):')
+                for i, nm in enumerate(names):
+                    col = rel[:, i][v[:, i] > 0]
+                    if len(col):
+                        import numpy as np
+                        print(f'      {nm:11s} {np.median(col):7.2f} {col.max():7.2f}   (n={len(col)})')
+            t = graph_time(ours, a.reps)
+            line += f' | {plan or "auto"}: {t:6.1f} us ({gflop / t * 1e-3:5.0f} TF) err {err:.1e}'
+        print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
