@@ -291,6 +291,174 @@ conv3x3_kernel(ConvArgs a)
     CONV_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Halo-tiled direct convolution for the large levels (H, W multiples of 16; Cout multiple of 128).
+//
+// An im2col GEMM re-reads every input pixel nine times through L2; at the ~10 TB/s the L2->LDS path sustains,
+// a 128x128 GEMM tile (64 FLOP/B) tops out near 640 TFLOP/s.  Here one workgroup owns a 16x16-pixel x 128-cout
+// tile, stages the 18x18-pixel HALO of one 64-channel chunk once and serves all nine taps from it by shifting
+// the LDS read address (pixel index + dy*18 + dx): per chunk 41 KB of activations + 9 x 16 KB of weights for
+// 37.7 MFLOP (~200 FLOP/B), so the MFMA pipe, not L2, is the limit.
+//   8 waves = 4 (pixel rows x4) x 2 (64 couts); MFMA tile = 16 couts x one 16-pixel tile row; per (chunk, tap) step
+//   a wave issues 32 v_mfma_f32_16x16x32_bf16 against 16 ds_read_b128.
+//   LDS: halo double-buffered (2 x 48 KB), weight tile in a 3-ring (3 x 16 KB): the next chunk's halo trickles in
+//   one DMA piece per step during taps 0..5, weights run two steps ahead; one raw s_barrier per step, counted
+//   vmcnt(2).  The halo image is PADDED, not XOR-swizzled: 144 B per pixel (8 channel slots + 1 pad slot, the pad
+//   being part of the lane-linear DMA stream), so a tap is a compile-time byte offset ((dy*18+dx)*144) folded into
+//   the ds_read immediate and ONE address register serves all 72 pixel-fragment reads of a chunk; with the XOR
+//   swizzle hipcc kept 72 precomputed addresses live, hit the 256-VGPR cap of 2 waves/SIMD and spilled (scratch
+//   loads are vector-memory ops: every one of them drained the DMA queue with vmcnt(0)).  9 is odd, so 16 pixels
+//   of a tile row land on 16 different 16-B bank slots; the k-chunk offset between the two halves of a
+//   ds_read_b128 lane group leaves a 2-way conflict on 7 of 16 slots.  The weight tile keeps the XOR swizzle.
+template <int BN>
+__global__ void __launch_bounds__(512)
+conv3x3_halo_kernel(ConvArgs a)
+{
+    constexpr int kHaloW = 18, kHaloPx = 18 * 18, kPitch = 144, kABytes = 6 * 512 * 16, kBBytes = BN * 128;
+    static_assert(kHaloPx * kPitch <= kABytes, "halo image must fit its buffer");
+    constexpr int PW = BN * 8 / 512;  // weight pieces per thread per step
+    constexpr int NT = BN / 32;       // 16-cout tiles per wave (2 cout groups of BN/2)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const bufA = lds, *const bufB = lds + 2 * kABytes;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    CONV_STAMP(0);
+    const int tiles_x = a.W >> 4, tiles_y = a.H >> 4;
+    const int n_tile = blockIdx.x % a.n_tiles;
+    int t = blockIdx.x / a.n_tiles;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, img = t / tiles_y;
+    const int n0 = n_tile * BN, chunks = a.Cin >> 6;
+
+    // ---- loaders
+    const unsigned short *a_ptr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
+        const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
+        const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+        const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        a_ptr[i] = ok ? a.x + ((size_t)(img * a.H + gy) * a.W + gx) * a.Cin + c * 8 : nullptr;
+    }
+    const unsigned short *w_ptr[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int p = tid + 512 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
+        w_ptr[i] = a.w + (size_t)(n0 + r) * 9 * a.Cin + c * 8;
+    }
+    const int piece = wave * 64 * 16;
+    auto issue_a = [&](int i, int q) {  // piece i of chunk q's halo
+        const unsigned short *src = a_ptr[i] ? a_ptr[i] + q * 64 : a.zero;
+        glds16(src, bufA + (q & 1) * kABytes + piece + i * 8192);
+    };
+    auto issue_b = [&](int q, int tap, int ring) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(w_ptr[i] + (size_t)tap * a.Cin + q * 64, bufB + ring * kBBytes + piece + i * 8192);
+    };
+
+    // ---- compute set-up
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fcol = lane & 15, fk = lane >> 4;
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int w_off[NT], w_sw[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = wn * (BN / 2) + n * 16 + fcol;
+        w_off[n] = r * 128;
+        w_sw[n] = (r >> 1) & 7;
+    }
+    // byte offset of (tile row wm*4, col fcol) at tap (0,0), k-chunk fk; rows m, taps and kh are immediates
+    const int px0 = ((wm * 4) * kHaloW + fcol) * kPitch + fk * 16;
+
+    // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_a(i, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 1, 1);
+    CONV_STAMP(1);
+
+#pragma unroll 1
+    for (int q = 0; q < chunks; ++q) {
+        const unsigned char *hA = bufA + (q & 1) * kABytes + px0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // everything but the two youngest DMA pieces (the weights of the NEXT step) has landed
+            if (tap == 8 && q == chunks - 1) wait_vm_lgkm0<0>();
+            else wait_vm_lgkm0<PW>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap == 0 && q == 0) CONV_STAMP(2);
+            if (tap < 6 && q + 1 < chunks) issue_a(tap, q + 1);
+            {   // weights two steps ahead: step (q, tap) + 2
+                const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9, q2 = tap + 2 < 9 ? q : q + 1;
+                if (q2 < chunks) issue_b(q2, t2, (tap + 2) % 3);
+            }
+            const unsigned char *wB = bufB + (tap % 3) * kBBytes;
+            const int shift = (tap / 3) * kHaloW + tap % 3;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 pf[4], wf[NT];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    pf[m] = *reinterpret_cast<const bf16x8 *>(hA + (m * kHaloW + shift) * kPitch + kh * 64);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    wf[n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+            }
+        }
+    }
+
+    CONV_STAMP(3);
+    // ---- epilogue through LDS (free now): acc + bias as fp32 into a [256 pixels][128 couts] image (pitch 528 B:
+    // 16-B skew per pixel keeps the 16 pixel-lanes of a ds_write_b128 on different banks), then every thread
+    // finishes 8-cout groups: fp32 from LDS + bf16 skip (16 B coalesced load) -> ReLU -> one rounding -> 16 B
+    // coalesced store.  Writing the accumulator layout straight out (8 B per lane, 512-B stride) took 12 us of a
+    // 47 us workgroup.
+    constexpr int kOPitch = BN * 4 + 16;
+    static_assert(256 * kOPitch <= 2 * kABytes + 3 * kBBytes, "output staging must fit the LDS of the main loop");
+    __syncthreads();  // all waves are done reading the last stage
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int px = (wm * 4 + m) * 16 + fcol;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int cl = wn * (BN / 2) + n * 16 + fk * 4;
+            *reinterpret_cast<f32x4 *>(lds + px * kOPitch + cl * 4) = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
+        }
+    }
+    __syncthreads();
+    constexpr int kGroups = 256 * BN / 8, kPerPx = BN / 8;
+    const size_t tile_px = (size_t)(img * a.H + ty * 16) * a.W + tx * 16;
+#pragma unroll
+    for (int i = 0; i < kGroups / 512; ++i) {
+        const int g = tid + 512 * i, px = g / kPerPx, cg = g % kPerPx;
+        const size_t off = (tile_px + (size_t)(px >> 4) * a.W + (px & 15)) * a.Cout + n0 + cg * 8;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (a.skip) {
+            const u16x8 sk = *reinterpret_cast<const u16x8 *>(a.skip + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bf2f(sk[j]);
+        }
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(a.relu ? fmaxf(v[j], 0.f) : v[j]);
+        *reinterpret_cast<u16x8 *>(a.out + off) = o;
+    }
+    CONV_STAMP(5);
+}
+
 // Second launch of the two-launch form: one workgroup per output tile sums the ksplit slabs (coalesced 16 B per
 // lane, all loads independent) and runs the epilogue with the thread mapping of the conv kernel.
 template <int BM, int BN>
@@ -362,6 +530,15 @@ size_t ws_layout(const Plan &p, size_t *counters_off, size_t *slabs_off)
 
 unsigned long long *g_stamps = nullptr;
 
+// Large levels go to the halo-tiled kernel (OG_CONV_HALO=0 disables, =1 forces it wherever the shape allows).
+bool use_halo(long M, int H, int W, int Cin, int Cout)
+{
+    if (H % 16 || W % 16 || Cout % 128 || Cin % 64) return false;
+    const char *e = getenv("OG_CONV_HALO");
+    if (e) return atoi(e) != 0;
+    return M >= 16384;
+}
+
 }  // namespace
 
 // Debug aid (tools/conv_bench.py --stamps): device buffer of [workgroups][8] u64 that later launches fill with
@@ -372,6 +549,7 @@ OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
 {
     Plan p;
     if (pixels <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || !make_plan(pixels, Cin, Cout, p)) return 0;
+    // (the halo kernel only needs the zero page, which every layout starts with)
     return ws_layout(p, nullptr, nullptr);
 }
 
@@ -386,6 +564,25 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     const long M = (long)N * H * W;
     OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 31), OG_EUNSUPPORTED, "%s: tensor too large", name);
     OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
+    hipStream_t st = (hipStream_t)stream;
+    if (use_halo(M, H, W, Cin, Cout)) {
+        ConvArgs h = {};
+        h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
+        h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
+        h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
+        h.stamps = g_stamps;
+        OG_REQUIRE(workspace_bytes >= kZeroPageBytes, OG_ENOSPC, "%s: workspace too small", name);
+        constexpr int lds = 2 * 6 * 512 * 16 + 3 * 128 * 128;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr = true;
+        }
+        const long blocks = (long)N * (H / 16) * (W / 16) * h.n_tiles;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<128>), dim3((unsigned)blocks), dim3(512), lds, st, h);
+        OG_LAUNCH_CHECK(name);
+        return OG_OK;
+    }
     Plan p;
     OG_REQUIRE(make_plan(M, Cin, Cout, p), OG_EUNSUPPORTED, "%s: no tile plan", name);
     OG_REQUIRE((size_t)p.m_tiles * p.n_tiles <= kMaxTiles, OG_EUNSUPPORTED, "%s: too many tiles", name);
@@ -408,7 +605,6 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     a.in_launch_reduce = p.in_launch;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
     const dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)p.ksplit);
-    hipStream_t st = (hipStream_t)stream;
 #define CONV_LAUNCH(BM_, ST_)                                                                                   \
     do {                                                                                                        \
         constexpr int lds_ = ST_ * 2 * BM_ * 128;                                                               \

@@ -77,6 +77,31 @@ def test_conv3x3_matches_torch(dev, shape, reduce_mode, monkeypatch):
     assert ws[:256].count_nonzero().item() == 0              # the zero page is never written
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256)])
+def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
+    """The halo-tiled kernel for the large levels (16x16-pixel x 128-cout tiles), forced on for small test shapes."""
+    import torch.nn.functional as F
+    monkeypatch.setenv("OG_CONV_HALO", "1")
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + cin)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    skip = torch.randn(n, cout, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    ws = torch.zeros(lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout), dtype=torch.uint8, device=dev)
+    for use_skip, relu in ((True, 1), (False, 0)):
+        ref = F.conv2d(x.float(), wt.float(), bias, 1, 1)
+        ref = F.relu(ref + skip.float()) if use_skip else ref
+        out = torch.full_like(skip, float('nan'))
+        _lib.check(lib.og_conv3x3_bf16(_lib.ptr(x), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None,
+                                       _lib.ptr(out), n, h, w, cin, cout, relu, _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(dev)), lib)
+        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 6e-3, f'relative error {err}'
+
+
 def test_conv3x3_rejects_bad_arguments(dev):
     lib = _lib.load()
     x = torch.zeros(1, 64, 4, 4, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)

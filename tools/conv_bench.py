@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from offsetguided_amd import _lib  # noqa: E402
 
 SHAPES = [(8, 5, 5, 512, 512), (8, 10, 10, 384, 384), (8, 20, 20, 384, 384), (8, 40, 40, 384, 384),
-          (8, 5, 5, 384, 512), (8, 40, 40, 256, 384), (8, 80, 80, 256, 256), (16, 20, 20, 384, 384), (16, 5, 5, 512, 512)]
+          (8, 5, 5, 384, 512), (8, 40, 40, 256, 384), (8, 80, 80, 256, 256), (16, 20, 20, 384, 384), (16, 5, 5, 512, 512),
+          (8, 160, 160, 256, 256), (16, 160, 160, 256, 256), (16, 80, 80, 256, 256)]
 
 
 _flush = None
@@ -50,7 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--plans', default='', help='comma list of "bm:ksplit" overrides to sweep, e.g. 64:4,64:8,128:2')
-    ap.add_argument('--only', type=int, default=-1)
+    ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--stamps', action='store_true', help='print in-kernel timeline (us) of one cold launch per plan')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -58,7 +59,7 @@ def main():
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)
     for si, (n, h, w, cin, cout) in enumerate(SHAPES):
-        if a.only >= 0 and si != a.only:
+        if a.only and si not in a.only:
             continue
         cl = torch.channels_last
         xs = [torch.randn(n, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(a.reps)]
@@ -98,7 +99,7 @@ def main():
             torch.cuda.synchronize()
             err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
             if a.stamps:
-                st = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+                st = torch.zeros(32768 * 8, dtype=torch.int64, device=dev)
                 _flush.fill_(1)
                 torch.cuda.synchronize()
                 lib.og_conv3x3_debug_stamps(_lib.ptr(st))
@@ -109,6 +110,11 @@ def main():
                 v = v[v[:, 0] > 0]
                 t0 = v[:, 0].min()
                 rel = (v - t0) / 100.0
+                import numpy as np
+                d = (v[:, [1, 2, 3, 5]] - v[:, [0, 1, 2, 3]]) / 100.0
+                ok = (v[:, 5] > 0) & (v[:, 3] > 0)
+                print('   per-workgroup phases (us, median): setup+issue %.2f | first data %.2f | loop %.2f | epilogue %.2f | total %.2f; kernel span %.1f'
+                      % (*np.median(d[ok], 0), np.median((v[ok, 5] - v[ok, 0]) / 100.0), (v[ok, 5].max() - t0) / 100.0))
                 names = ['start', 'issued', 'first data', 'loop end', 'ticket', 'end(last)']
                 print(f'   [{plan or "auto"}] {len(v)} workgroups; us since first start (median / max):')
                 for i, nm in enumerate(names):
