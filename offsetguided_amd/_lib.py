@@ -11,6 +11,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libog_decoder.so")
+if os.environ.get("OG_DECODER_LIB"):  # alternative build of the same ABI (kernel A/B experiments)
+    LIB_PATH = os.environ["OG_DECODER_LIB"]
 
 OG_OK, OG_EINVAL, OG_ENOSPC, OG_EHIP, OG_EUNSUPPORTED = 0, -1, -2, -3, -4
 ABI_VERSION = 1

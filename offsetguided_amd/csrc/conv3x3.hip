@@ -301,29 +301,43 @@ conv3x3_kernel(ConvArgs a)
 // 37.7 MFLOP (~200 FLOP/B), so the MFMA pipe, not L2, is the limit.
 //   8 waves = 4 (pixel rows x4) x 2 (64 couts); MFMA tile = 16 couts x one 16-pixel tile row; per (chunk, tap) step
 //   a wave issues 32 v_mfma_f32_16x16x32_bf16 against 16 ds_read_b128.
-//   LDS: halo double-buffered (2 x 48 KB), weight tile in a 3-ring (3 x 16 KB): the next chunk's halo trickles in
-//   one DMA piece per step during taps 0..5, weights run two steps ahead; one raw s_barrier per step, counted
-//   vmcnt(2).  The halo image is PADDED, not XOR-swizzled: 144 B per pixel (8 channel slots + 1 pad slot, the pad
+//   LDS: halo double-buffered (2 x 48 KB), weight tile in a 4-ring (4 x 16 KB) = all 160 KiB: the next chunk's halo
+//   trickles in one DMA piece per step during taps 0..5, weights run three steps ahead, counted vmcnt(2).
+//   Every step is two barrier-separated phases, R (LDS fragment reads + DMA issue) and M (32 MFMA), and the two
+//   waves that share a SIMD run them in opposite order (ping-pong): with both in lockstep the MFMA pipe idled
+//   through every fragment fetch (0.88 us per step against 0.43 us of MFMA issue).
+//   The halo image is PADDED, not XOR-swizzled: 144 B per pixel (8 channel slots + 1 pad slot, the pad
 //   being part of the lane-linear DMA stream), so a tap is a compile-time byte offset ((dy*18+dx)*144) folded into
 //   the ds_read immediate and ONE address register serves all 72 pixel-fragment reads of a chunk; with the XOR
 //   swizzle hipcc kept 72 precomputed addresses live, hit the 256-VGPR cap of 2 waves/SIMD and spilled (scratch
 //   loads are vector-memory ops: every one of them drained the DMA queue with vmcnt(0)).  9 is odd, so 16 pixels
 //   of a tile row land on 16 different 16-B bank slots; the k-chunk offset between the two halves of a
 //   ds_read_b128 lane group leaves a 2-way conflict on 7 of 16 slots.  The weight tile keeps the XOR swizzle.
-template <int BN>
+#ifndef HALO_EXP
+#define HALO_EXP 0
+#endif
+// TW x TH = pixel tile (TW*TH a multiple of 16*WM), WM = waves along the pixels (8/WM along the 128 couts).
+// A 16-pixel MFMA column block is 16 consecutive pixels of the tile in row-major order (it may wrap over tile rows:
+// only the per-lane base address knows), so TW need not be a multiple of 16: 16x16 tiles serve 160x160 / 80x80,
+// full-width 40x4 tiles serve 40x40.
+template <int TW, int TH, int WM>
 __global__ void __launch_bounds__(512)
 conv3x3_halo_kernel(ConvArgs a)
 {
-    constexpr int kHaloW = 18, kHaloPx = 18 * 18, kPitch = 144, kABytes = 6 * 512 * 16, kBBytes = BN * 128;
-    static_assert(kHaloPx * kPitch <= kABytes, "halo image must fit its buffer");
-    constexpr int PW = BN * 8 / 512;  // weight pieces per thread per step
-    constexpr int NT = BN / 32;       // 16-cout tiles per wave (2 cout groups of BN/2)
+    constexpr int BN = 128, WN = 8 / WM;
+    constexpr int kHaloW = TW + 2, kHaloPx = (TW + 2) * (TH + 2), kPitch = 144;
+    constexpr int NPA = (kHaloPx * 9 + 511) / 512;          // halo DMA pieces per thread (9 16-B slots per pixel)
+    constexpr int kABytes = NPA * 512 * 16, kBBytes = BN * 128;
+    constexpr int PW = BN * 8 / 512;                         // weight pieces per thread per step
+    constexpr int MT = TW * TH / 16 / WM, NT = 8 / WN;       // 16-pixel / 16-cout tiles per wave
+    static_assert(TW * TH % (16 * WM) == 0 && 8 % WM == 0 && NPA <= 6, "unsupported tile");
+    static_assert(2 * kABytes + 4 * kBBytes <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char *const bufA = lds, *const bufB = lds + 2 * kABytes;
+    unsigned char *const bufA = lds, *const bufB = lds + 2 * kABytes;  // [A0 | A1 | B0..B3]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     CONV_STAMP(0);
-    const int tiles_x = a.W >> 4, tiles_y = a.H >> 4;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     const int n_tile = blockIdx.x % a.n_tiles;
     int t = blockIdx.x / a.n_tiles;
     const int tx = t % tiles_x;
@@ -332,12 +346,12 @@ conv3x3_halo_kernel(ConvArgs a)
     const int n0 = n_tile * BN, chunks = a.Cin >> 6;
 
     // ---- loaders
-    const unsigned short *a_ptr[6];
+    const unsigned short *a_ptr[NPA];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NPA; ++i) {
         const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
         const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
-        const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+        const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
         const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         a_ptr[i] = ok ? a.x + ((size_t)(img * a.H + gy) * a.W + gx) * a.Cin + c * 8 : nullptr;
     }
@@ -358,65 +372,93 @@ conv3x3_halo_kernel(ConvArgs a)
     };
 
     // ---- compute set-up
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fcol = lane & 15, fk = lane >> 4;
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int w_off[NT], w_sw[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int r = wn * (BN / 2) + n * 16 + fcol;
+        const int r = (wn * NT + n) * 16 + fcol;
         w_off[n] = r * 128;
         w_sw[n] = (r >> 1) & 7;
     }
-    // byte offset of (tile row wm*4, col fcol) at tap (0,0), k-chunk fk; rows m, taps and kh are immediates
-    const int px0 = ((wm * 4) * kHaloW + fcol) * kPitch + fk * 16;
-
-    // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+    // byte offset of this lane's pixel of column block m at tap (0,0), k-chunk fk; taps and kh are immediates
+    int px_off[MT];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_a(i, 0);
+    for (int m = 0; m < MT; ++m) {
+        const int lp = (wm * MT + m) * 16 + fcol;
+        px_off[m] = ((lp / TW) * kHaloW + lp % TW) * kPitch + fk * 16;
+    }
+
+    // ---- prologue: halo of chunk 0, weights of steps 0..2
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) issue_a(i, 0);
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
+    issue_b(0, 2, 2);
     CONV_STAMP(1);
+    wait_vm_lgkm0<2 * PW>();
+    __builtin_amdgcn_s_barrier();
+    // Ping-pong: waves 4..7 (the second wave on every SIMD) run one phase behind waves 0..3, so that on each SIMD
+    // one wave is in its MFMA phase while the other fetches fragments from LDS.  They take one extra barrier here,
+    // waves 0..3 take it after the loop.
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    CONV_STAMP(2);
 
+    // Phase R(s): counted wait, DMA issue (weights of step s+3 into the 4-ring, one halo piece of the next chunk),
+    // 16 ds_read_b128, lgkmcnt(0) | barrier | phase M(s): 32 MFMA | barrier.
+    // DMA -> ds_read ordering: a wave's pieces of B(s+1) have landed at its wait in R(s) (everything but the two
+    // youngest pieces, B(s+2)); the late group's R(s) is one barrier before the early group's R(s+1).  Ring slot of
+    // B(s+3) = slot of B(s-1), last read in R(s-1) by both groups, at least one barrier (with lgkmcnt(0)) ago.
 #pragma unroll 1
     for (int q = 0; q < chunks; ++q) {
-        const unsigned char *hA = bufA + (q & 1) * kABytes + px0;
+        const unsigned char *hA = bufA + (q & 1) * kABytes;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // everything but the two youngest DMA pieces (the weights of the NEXT step) has landed
-            if (tap == 8 && q == chunks - 1) wait_vm_lgkm0<0>();
-            else wait_vm_lgkm0<PW>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (tap == 0 && q == 0) CONV_STAMP(2);
-            if (tap < 6 && q + 1 < chunks) issue_a(tap, q + 1);
-            {   // weights two steps ahead: step (q, tap) + 2
-                const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9, q2 = tap + 2 < 9 ? q : q + 1;
-                if (q2 < chunks) issue_b(q2, t2, (tap + 2) % 3);
+            const bool newer_in_flight = tap < 7 || q + 1 < chunks;  // B(s+2) exists
+            if (newer_in_flight) wait_vm_lgkm0<PW>();
+            else wait_vm_lgkm0<0>();
+            // (issuing the DMA between the MFMA halves instead measured 3-8 % slower)
+            if (tap < NPA && q + 1 < chunks) issue_a(tap, q + 1);
+            {
+                const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9, q3 = tap + 3 < 9 ? q : q + 1;
+                if (q3 < chunks) issue_b(q3, t3, (q + tap + 3) & 3);
             }
-            const unsigned char *wB = bufB + (tap % 3) * kBBytes;
-            const int shift = (tap / 3) * kHaloW + tap % 3;
+            const unsigned char *wB = bufB + ((q + tap) & 3) * kBBytes;
+            const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
+            bf16x8 pf[2][MT], wf[2][NT];
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
-                bf16x8 pf[4], wf[NT];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    pf[m] = *reinterpret_cast<const bf16x8 *>(hA + (m * kHaloW + shift) * kPitch + kh * 64);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    wf[n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+                for (int m = 0; m < MT; ++m)
+                    pf[kh][m] = *reinterpret_cast<const bf16x8 *>(hA + px_off[m] + shift + kh * 64);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+                    wf[kh][n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][n], pf[kh][m], acc[n][m], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
 
     CONV_STAMP(3);
     // ---- epilogue through LDS (free now): acc + bias as fp32 into a [256 pixels][128 couts] image (pitch 528 B:
@@ -424,25 +466,26 @@ conv3x3_halo_kernel(ConvArgs a)
     // finishes 8-cout groups: fp32 from LDS + bf16 skip (16 B coalesced load) -> ReLU -> one rounding -> 16 B
     // coalesced store.  Writing the accumulator layout straight out (8 B per lane, 512-B stride) took 12 us of a
     // 47 us workgroup.
-    constexpr int kOPitch = BN * 4 + 16;
-    static_assert(256 * kOPitch <= 2 * kABytes + 3 * kBBytes, "output staging must fit the LDS of the main loop");
+    constexpr int kOPitch = BN * 4 + 16, kTilePx = TW * TH;
+    static_assert(kTilePx * kOPitch <= 2 * kABytes + 4 * kBBytes, "output staging must fit the LDS of the main loop");
     __syncthreads();  // all waves are done reading the last stage
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int px = (wm * 4 + m) * 16 + fcol;
+    for (int m = 0; m < MT; ++m) {
+        const int px = (wm * MT + m) * 16 + fcol;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int cl = wn * (BN / 2) + n * 16 + fk * 4;
+            const int cl = (wn * NT + n) * 16 + fk * 4;
             *reinterpret_cast<f32x4 *>(lds + px * kOPitch + cl * 4) = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
         }
     }
     __syncthreads();
-    constexpr int kGroups = 256 * BN / 8, kPerPx = BN / 8;
-    const size_t tile_px = (size_t)(img * a.H + ty * 16) * a.W + tx * 16;
+    constexpr int kPerPx = BN / 8, kGroups = kTilePx * kPerPx;
+    static_assert(kGroups % 512 == 0, "tile pixels must be a multiple of 32");
+    const size_t tile_px = (size_t)(img * a.H + ty * TH) * a.W + tx * TW;
 #pragma unroll
     for (int i = 0; i < kGroups / 512; ++i) {
         const int g = tid + 512 * i, px = g / kPerPx, cg = g % kPerPx;
-        const size_t off = (tile_px + (size_t)(px >> 4) * a.W + (px & 15)) * a.Cout + n0 + cg * 8;
+        const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + n0 + cg * 8;
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32);
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32 + 16);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -530,13 +573,14 @@ size_t ws_layout(const Plan &p, size_t *counters_off, size_t *slabs_off)
 
 unsigned long long *g_stamps = nullptr;
 
-// Large levels go to the halo-tiled kernel (OG_CONV_HALO=0 disables, =1 forces it wherever the shape allows).
-bool use_halo(long M, int H, int W, int Cin, int Cout)
+// Large levels go to the halo-tiled kernel: 1 = 16x16 tiles (H, W multiples of 16), 2 = 40x4 full-width tiles
+// (W == 40, H multiple of 4), 0 = not applicable.  OG_CONV_HALO=0 disables, =1 forces it wherever the shape allows.
+int halo_kind(long M, int H, int W, int Cin, int Cout)
 {
-    if (H % 16 || W % 16 || Cout % 128 || Cin % 64) return false;
-    const char *e = getenv("OG_CONV_HALO");
-    if (e) return atoi(e) != 0;
-    return M >= 16384;
+    if (Cout % 128 || Cin % 64) return 0;
+    const int kind = (H % 16 == 0 && W % 16 == 0) ? 1 : (W == 40 && H % 4 == 0) ? 2 : 0;
+    if (const char *e = getenv("OG_CONV_HALO")) return atoi(e) != 0 ? kind : 0;
+    return M >= 8192 ? kind : 0;
 }
 
 }  // namespace
@@ -565,21 +609,28 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 31), OG_EUNSUPPORTED, "%s: tensor too large", name);
     OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
     hipStream_t st = (hipStream_t)stream;
-    if (use_halo(M, H, W, Cin, Cout)) {
+    if (const int kind = halo_kind(M, H, W, Cin, Cout)) {
         ConvArgs h = {};
         h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
         h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
         h.stamps = g_stamps;
         OG_REQUIRE(workspace_bytes >= kZeroPageBytes, OG_ENOSPC, "%s: workspace too small", name);
-        constexpr int lds = 2 * 6 * 512 * 16 + 3 * 128 * 128;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr = true;
-        }
-        const long blocks = (long)N * (H / 16) * (W / 16) * h.n_tiles;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<128>), dim3((unsigned)blocks), dim3(512), lds, st, h);
+#define HALO_LAUNCH(TW_, TH_, WM_)                                                                              \
+    do {                                                                                                        \
+        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 9 + 511) / 512, lds_ = 2 * npa_ * 8192 + 4 * 128 * 128;   \
+        static bool attr_ = false;                                                                              \
+        if (!attr_) {                                                                                           \
+            (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<TW_, TH_, WM_>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
+            attr_ = true;                                                                                       \
+        }                                                                                                       \
+        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                       \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(512), lds_, st, h); \
+    } while (0)
+        if (kind == 1) HALO_LAUNCH(16, 16, 4);
+        else HALO_LAUNCH(40, 4, 2);
+#undef HALO_LAUNCH
         OG_LAUNCH_CHECK(name);
         return OG_OK;
     }

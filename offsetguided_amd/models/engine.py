@@ -55,9 +55,9 @@ def _epilogue(y, bias32, bias_lp, skip, relu, fused):
 # Layers with at most this many output pixels (N*H*W) run on the hand-written split-K MFMA kernel
 # (og_conv3x3_bf16, epilogue fused) instead of MIOpen + og_bias_act_bf16: the 20x20 / 10x10 / 5x5 levels at bs8.
 CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
-# ... and layers with at least this many pixels whose H, W are multiples of 16 (the 160x160 / 80x80 levels) run on its
-# halo-tiled variant; in between (40x40) MIOpen's kernels stay.
-CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '16384'))
+# ... and layers with at least this many pixels run on its halo-tiled variant where a tile shape exists: H, W multiples
+# of 16 (the 160x160 / 80x80 levels) or W == 40 (the 40x40 level).
+CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
 _conv_ws = {}
 
 
@@ -90,7 +90,8 @@ class _Conv:
     def __call__(self, x, skip=None):
         n, c, h, w = x.shape
         if self.hip3x3 and (n * h * w <= CONV3X3_MAX_PIXELS or (
-                n * h * w >= CONV3X3_HALO_MIN_PIXELS and h % 16 == 0 and w % 16 == 0 and self.w.shape[0] % 128 == 0)):
+                n * h * w >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
+                and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
             return self._hip(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
 

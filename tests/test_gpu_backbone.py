@@ -77,9 +77,11 @@ def test_conv3x3_matches_torch(dev, shape, reduce_mode, monkeypatch):
     assert ws[:256].count_nonzero().item() == 0              # the zero page is never written
 
 
-@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256)])
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256),
+                                   (1, 4, 40, 64, 128), (2, 40, 40, 384, 384), (1, 12, 40, 128, 256)])
 def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
-    """The halo-tiled kernel for the large levels (16x16-pixel x 128-cout tiles), forced on for small test shapes."""
+    """The halo-tiled kernel for the large levels (16x16-pixel tiles; 40x4 full-width tiles when W == 40) x 128 couts,
+    forced on for small test shapes."""
     import torch.nn.functional as F
     monkeypatch.setenv("OG_CONV_HALO", "1")
     n, h, w, cin, cout = shape
