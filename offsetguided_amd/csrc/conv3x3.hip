@@ -394,6 +394,20 @@ conv3x3_halo_kernel(ConvArgs a)
         px_off[m] = ((lp / TW) * kHaloW + lp % TW) * kPitch + fk * 16;
     }
 
+    // global pixel index of this lane's pixel of column block m (epilogue + residual prefetch)
+    size_t out_px[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int lp = (wm * MT + m) * 16 + fcol;
+        out_px[m] = (size_t)(img * a.H + ty * TH + lp / TW) * a.W + tx * TW + lp % TW;
+    }
+    const bool has_skip = a.skip != nullptr;
+    u16x4 sk[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) sk[n][m] = (u16x4){0, 0, 0, 0};
+
     // ---- prologue: halo of chunk 0, weights of steps 0..2
 #pragma unroll
     for (int i = 0; i < NPA; ++i) issue_a(i, 0);
@@ -419,14 +433,24 @@ conv3x3_halo_kernel(ConvArgs a)
         const unsigned char *hA = bufA + (q & 1) * kABytes;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const bool newer_in_flight = tap < 7 || q + 1 < chunks;  // B(s+2) exists
-            if (newer_in_flight) wait_vm_lgkm0<PW>();
-            else wait_vm_lgkm0<0>();
+            // B(s+2) exists unless this is one of the last two steps; behind the last weight DMA (tap 5 of the last
+            // chunk) ride the NT*MT residual loads, which the counted waits of taps 6..8 must leave in flight too
+            const bool last = q + 1 == chunks;
+            if (tap < 6 || !last) wait_vm_lgkm0<PW>();
+            else if (!has_skip) { if (tap == 6) wait_vm_lgkm0<PW>(); else wait_vm_lgkm0<0>(); }
+            else { if (tap == 6) wait_vm_lgkm0<PW + NT * MT>(); else wait_vm_lgkm0<NT * MT>(); }
             // (issuing the DMA between the MFMA halves instead measured 3-8 % slower)
             if (tap < NPA && q + 1 < chunks) issue_a(tap, q + 1);
             {
                 const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9, q3 = tap + 3 < 9 ? q : q + 1;
                 if (q3 < chunks) issue_b(q3, t3, (q + tap + 3) & 3);
+            }
+            if (tap == 5 && last && has_skip) {  // residual operand in accumulator layout: 8 B per lane, latency hidden
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        sk[n][m] = *reinterpret_cast<const u16x4 *>(a.skip + out_px[m] * a.Cout + n0 + (wn * NT + n) * 16 + fk * 4);
             }
             const unsigned char *wB = bufB + ((q + tap) & 3) * kBBytes;
             const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
@@ -461,12 +485,12 @@ conv3x3_halo_kernel(ConvArgs a)
     if (wave < 4) __builtin_amdgcn_s_barrier();
 
     CONV_STAMP(3);
-    // ---- epilogue through LDS (free now): acc + bias as fp32 into a [256 pixels][128 couts] image (pitch 528 B:
-    // 16-B skew per pixel keeps the 16 pixel-lanes of a ds_write_b128 on different banks), then every thread
-    // finishes 8-cout groups: fp32 from LDS + bf16 skip (16 B coalesced load) -> ReLU -> one rounding -> 16 B
-    // coalesced store.  Writing the accumulator layout straight out (8 B per lane, 512-B stride) took 12 us of a
-    // 47 us workgroup.
-    constexpr int kOPitch = BN * 4 + 16, kTilePx = TW * TH;
+    // ---- epilogue: bias + residual (prefetched above) + ReLU + the one rounding happen in the accumulator layout;
+    // the bf16 tile then goes through LDS ([tile pixels][128 couts], pitch 272 B: conflict-free ds_write_b64) so that
+    // global stores are 16 B per lane, 256 B contiguous per pixel.  (Storing the accumulator layout straight out
+    // -- 8 B per lane at a 512-B stride -- took 12 us of a 47 us workgroup; staging fp32 and adding the residual
+    // after it 8 us.)
+    constexpr int kOPitch = BN * 2 + 16, kTilePx = TW * TH;
     static_assert(kTilePx * kOPitch <= 2 * kABytes + 4 * kBBytes, "output staging must fit the LDS of the main loop");
     __syncthreads();  // all waves are done reading the last stage
 #pragma unroll
@@ -475,7 +499,14 @@ conv3x3_halo_kernel(ConvArgs a)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int cl = (wn * NT + n) * 16 + fk * 4;
-            *reinterpret_cast<f32x4 *>(lds + px * kOPitch + cl * 4) = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
+            f32x4 v = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
+            u16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float f = v[jj] + bf2f(sk[n][m][jj]);
+                o[jj] = f2bf(a.relu ? fmaxf(f, 0.f) : f);
+            }
+            *reinterpret_cast<u16x4 *>(lds + px * kOPitch + cl * 2) = o;
         }
     }
     __syncthreads();
@@ -486,18 +517,7 @@ conv3x3_halo_kernel(ConvArgs a)
     for (int i = 0; i < kGroups / 512; ++i) {
         const int g = tid + 512 * i, px = g / kPerPx, cg = g % kPerPx;
         const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + n0 + cg * 8;
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32);
-        const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + px * kOPitch + cg * 32 + 16);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (a.skip) {
-            const u16x8 sk = *reinterpret_cast<const u16x8 *>(a.skip + off);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bf2f(sk[j]);
-        }
-        u16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(a.relu ? fmaxf(v[j], 0.f) : v[j]);
-        *reinterpret_cast<u16x8 *>(a.out + off) = o;
+        *reinterpret_cast<u16x8 *>(a.out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
     }
     CONV_STAMP(5);
 }
