@@ -58,16 +58,22 @@ CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
 # ... and layers with at least this many pixels run on its halo-tiled variant where a tile shape exists: H, W multiples
 # of 16 (the 160x160 / 80x80 levels) or W == 40 (the 40x40 level).
 CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
+# The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
+# models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
+# captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
+BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 _conv_ws = {}
+_branch = 0      # which concurrent branch is issuing work: 0 = trunk, d+1 = up1 branch of level d
 
 
 def _conv3x3_workspace(device, nbytes):
-    """One zero-initialised scratch per device for og_conv3x3_bf16 (zero page + split-K slabs).  Layers run
-    back to back on one stream, so they share it; it only ever grows outside graph capture."""
-    buf = _conv_ws.get(device.index)
+    """One zero-initialised scratch per (device, concurrent branch) for og_conv3x3_bf16 (zero page + split-K slabs).
+    Layers of one branch run back to back on one stream, so they share it; it only ever grows outside graph capture."""
+    key = (device.index, _branch)
+    buf = _conv_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         assert not torch.cuda.is_current_stream_capturing(), 'conv3x3 workspace must be sized before graph capture'
-        buf = _conv_ws[device.index] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        buf = _conv_ws[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
     return buf
 
 
@@ -135,16 +141,36 @@ def _run(seq, x):
 
 
 class _Level:
-    def __init__(self, m, dtype, fused):
-        self.fused = fused
+    def __init__(self, m, dtype, fused, depth=0):
+        self.fused, self.depth, self._side = fused, depth, None
         self.up1, self.low1, self.low3 = _seq(m.up1, dtype, fused), _seq(m.low1, dtype, fused), _seq(m.low3, dtype, fused)
-        self.low2 = _Level(m.low2, dtype, fused) if isinstance(m.low2, HourglassLevel) else _seq(m.low2, dtype, fused)
+        self.low2 = (_Level(m.low2, dtype, fused, depth + 1) if isinstance(m.low2, HourglassLevel)
+                     else _seq(m.low2, dtype, fused))
 
-    def __call__(self, x):
+    def _lower(self, x):
         low = _run(self.low1, x)
         low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
-        low = _run(self.low3, low)
-        up = _run(self.up1, x)
+        return _run(self.low3, low)
+
+    def __call__(self, x):
+        global _branch
+        if BRANCHES and x.is_cuda:
+            cur = torch.cuda.current_stream(x.device)
+            if self._side is None:
+                # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work
+                prio = int(os.environ.get('OG_ENGINE_SIDE_PRIORITY', '0'))
+                self._side = torch.cuda.Stream(x.device, priority=prio)
+            self._side.wait_stream(cur)                      # fork: up1 only needs x
+            outer = _branch
+            with torch.cuda.stream(self._side):
+                _branch = self.depth + 1
+                up = _run(self.up1, x)
+                _branch = outer
+            low = self._lower(x)
+            cur.wait_stream(self._side)                      # join before the merge
+        else:
+            low = self._lower(x)
+            up = _run(self.up1, x)
         if self.fused:  # up += nearest_x2(low) in one pass
             n, c, h, w = up.shape
             lib = _lib.load()
@@ -214,7 +240,9 @@ class InferenceEngine:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
+        # (capturing the trunk on a high-priority stream, OG_ENGINE_TRUNK_PRIORITY=1, measured no difference)
+        trunk = torch.cuda.Stream(self.device, priority=-1) if int(os.environ.get('OG_ENGINE_TRUNK_PRIORITY', '0')) else None
+        with torch.no_grad(), torch.cuda.graph(self._graph, stream=trunk):
             self._out = self._forward(self._static_in)
 
     @torch.no_grad()
