@@ -49,6 +49,7 @@ struct ConvArgs {
     const unsigned short *zero;  // >= 16 B of zeros
     int N, H, W, Cin, Cout, M;
     int n_tiles, steps_per_split, ksplit, relu;
+    int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
 };
@@ -72,6 +73,14 @@ __device__ __forceinline__ void glds16(const void *g, unsigned char *l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
+
+// LDS-DMA through a buffer descriptor: 32-bit per-lane offset + scalar offset, and an out-of-range lane offset reads
+// as zero -- the convolution's zero padding without a branch, a second base pointer or 64-bit address registers.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char *l)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 0);
+}
+constexpr uint32_t kOobOffset = 0x80000000u;  // beyond any tensor this library accepts (< 2 GiB)
 
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0()
@@ -345,40 +354,38 @@ conv3x3_halo_kernel(ConvArgs a)
     const int ty = t % tiles_y, img = t / tiles_y;
     const int n0 = n_tile * BN, chunks = a.Cin >> 6;
 
-    // ---- loaders
-    const unsigned short *a_ptr[NPA];
+    // ---- loaders: byte offsets into x / w for buffer-addressed LDS-DMA; out-of-image halo pixels, the pad slot and
+    // pieces past the halo get an out-of-range offset and arrive as zeros
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.w), 0, a.w_bytes, 0x00020000);
+    uint32_t a_off[NPA];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
         const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
         const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
         const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
         const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        a_ptr[i] = ok ? a.x + ((size_t)(img * a.H + gy) * a.W + gx) * a.Cin + c * 8 : nullptr;
+        a_off[i] = ok ? (uint32_t)((((img * a.H + gy) * a.W + gx) * a.Cin + c * 8) * 2) : kOobOffset;
     }
-    const unsigned short *w_ptr[PW];
+    uint32_t w_off_g[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = tid + 512 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_ptr[i] = a.w + (size_t)(n0 + r) * 9 * a.Cin + c * 8;
+        w_off_g[i] = (uint32_t)(((n0 + r) * 9 * a.Cin + c * 8) * 2);
     }
     const int piece = wave * 64 * 16;
     auto issue_a = [&](int i, int q) {  // piece i of chunk q's halo
-        const unsigned short *src = a_ptr[i] ? a_ptr[i] + q * 64 : a.zero;
-        glds16(src, bufA + (q & 1) * kABytes + piece + i * 8192);
+        blds16(xr, a_off[i], q * 128, bufA + (q & 1) * kABytes + piece + i * 8192);
     };
     auto issue_b = [&](int q, int tap, int ring) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(w_ptr[i] + (size_t)tap * a.Cin + q * 64, bufB + ring * kBBytes + piece + i * 8192);
+        for (int i = 0; i < PW; ++i) blds16(wr, w_off_g[i], (tap * a.Cin + q * 64) * 2, bufB + ring * kBBytes + piece + i * 8192);
     };
 
     // ---- compute set-up
     const int wm = wave / WN, wn = wave % WN;
     const int fcol = lane & 15, fk = lane >> 4;
     f32x4 acc[NT][MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int w_off[NT], w_sw[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -402,11 +409,6 @@ conv3x3_halo_kernel(ConvArgs a)
         out_px[m] = (size_t)(img * a.H + ty * TH + lp / TW) * a.W + tx * TW + lp % TW;
     }
     const bool has_skip = a.skip != nullptr;
-    u16x4 sk[NT][MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) sk[n][m] = (u16x4){0, 0, 0, 0};
 
     // ---- prologue: halo of chunk 0, weights of steps 0..2
 #pragma unroll
@@ -416,6 +418,23 @@ conv3x3_halo_kernel(ConvArgs a)
     issue_b(0, 2, 2);
     CONV_STAMP(1);
     wait_vm_lgkm0<2 * PW>();
+    // The residual operand initialises the accumulators (D = skip + sum of products) instead of being added in the
+    // epilogue: its 8-B-per-lane loads are in flight while the first stages land, and the main loop carries neither
+    // 32 extra registers nor extra vmcnt cases (prefetching it during the last taps stalled those steps).
+    {
+        u16x4 sk[NT][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                sk[n][m] = has_skip ? *reinterpret_cast<const u16x4 *>(a.skip + out_px[m] * a.Cout + n0 + (wn * NT + n) * 16 + fk * 4)
+                                    : (u16x4){0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[n][m] = (f32x4){bf2f(sk[n][m][0]), bf2f(sk[n][m][1]), bf2f(sk[n][m][2]), bf2f(sk[n][m][3])};
+    }
     __builtin_amdgcn_s_barrier();
     // Ping-pong: waves 4..7 (the second wave on every SIMD) run one phase behind waves 0..3, so that on each SIMD
     // one wave is in its MFMA phase while the other fetches fragments from LDS.  They take one extra barrier here,
@@ -433,24 +452,14 @@ conv3x3_halo_kernel(ConvArgs a)
         const unsigned char *hA = bufA + (q & 1) * kABytes;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // B(s+2) exists unless this is one of the last two steps; behind the last weight DMA (tap 5 of the last
-            // chunk) ride the NT*MT residual loads, which the counted waits of taps 6..8 must leave in flight too
-            const bool last = q + 1 == chunks;
-            if (tap < 6 || !last) wait_vm_lgkm0<PW>();
-            else if (!has_skip) { if (tap == 6) wait_vm_lgkm0<PW>(); else wait_vm_lgkm0<0>(); }
-            else { if (tap == 6) wait_vm_lgkm0<PW + NT * MT>(); else wait_vm_lgkm0<NT * MT>(); }
+            // B(s+2) exists unless this is one of the last two steps
+            if (tap < 7 || q + 1 < chunks) wait_vm_lgkm0<PW>();
+            else wait_vm_lgkm0<0>();
             // (issuing the DMA between the MFMA halves instead measured 3-8 % slower)
             if (tap < NPA && q + 1 < chunks) issue_a(tap, q + 1);
             {
                 const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9, q3 = tap + 3 < 9 ? q : q + 1;
                 if (q3 < chunks) issue_b(q3, t3, (q + tap + 3) & 3);
-            }
-            if (tap == 5 && last && has_skip) {  // residual operand in accumulator layout: 8 B per lane, latency hidden
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        sk[n][m] = *reinterpret_cast<const u16x4 *>(a.skip + out_px[m] * a.Cout + n0 + (wn * NT + n) * 16 + fk * 4);
             }
             const unsigned char *wB = bufB + ((q + tap) & 3) * kBBytes;
             const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
@@ -485,7 +494,7 @@ conv3x3_halo_kernel(ConvArgs a)
     if (wave < 4) __builtin_amdgcn_s_barrier();
 
     CONV_STAMP(3);
-    // ---- epilogue: bias + residual (prefetched above) + ReLU + the one rounding happen in the accumulator layout;
+    // ---- epilogue: bias + ReLU + the one rounding happen in the accumulator layout (the residual is already in);
     // the bf16 tile then goes through LDS ([tile pixels][128 couts], pitch 272 B: conflict-free ds_write_b64) so that
     // global stores are 16 B per lane, 256 B contiguous per pixel.  (Storing the accumulator layout straight out
     // -- 8 B per lane at a 512-B stride -- took 12 us of a 47 us workgroup; staging fp32 and adding the residual
@@ -502,10 +511,7 @@ conv3x3_halo_kernel(ConvArgs a)
             f32x4 v = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
             u16x4 o;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float f = v[jj] + bf2f(sk[n][m][jj]);
-                o[jj] = f2bf(a.relu ? fmaxf(f, 0.f) : f);
-            }
+            for (int jj = 0; jj < 4; ++jj) o[jj] = f2bf(a.relu ? fmaxf(v[jj], 0.f) : v[jj]);
             *reinterpret_cast<u16x4 *>(lds + px * kOPitch + cl * 2) = o;
         }
     }
@@ -626,7 +632,7 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     OG_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0, OG_EUNSUPPORTED,
                "%s: channels must be multiples of 64 (got %d -> %d)", name, Cin, Cout);
     const long M = (long)N * H * W;
-    OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 31), OG_EUNSUPPORTED, "%s: tensor too large", name);
+    OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
     OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
     hipStream_t st = (hipStream_t)stream;
     if (const int kind = halo_kind(M, H, W, Cin, Cout)) {
@@ -635,6 +641,8 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
         h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
         h.stamps = g_stamps;
+        h.x_bytes = (int)(M * Cin * 2);
+        h.w_bytes = Cout * 9 * Cin * 2;
         OG_REQUIRE(workspace_bytes >= kZeroPageBytes, OG_ENOSPC, "%s: workspace too small", name);
 #define HALO_LAUNCH(TW_, TH_, WM_)                                                                              \
     do {                                                                                                        \
