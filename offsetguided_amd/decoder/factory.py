@@ -8,6 +8,7 @@ but runs the whole post-processing on the GPU:
 with a single device->host copy of the finished poses.  No multiprocessing.Pool is created.
 """
 import logging
+import os
 import re
 
 import torch
@@ -85,6 +86,10 @@ class PostProcess(torch.nn.Module):
         # structure and the HBM-roofline path.  True: K1-fused upsamples inside the NMS kernel
         # (identical results, 16x less HBM traffic).
         self.fused_upsample = False
+        # submit(): grouping (one workgroup per image, latency-bound) and the pose D2H copy run on their own stream, so
+        # the caller's next launches (the following batch's backbone) do not queue behind them
+        self.group_on_side_stream = os.environ.get('OG_GROUP_SIDE_STREAM', '1') != '0'
+        self._side = {}
         self._pinned, self._flip = {}, 0
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
                  'device-resident grouping', feat_stage, hmp_index, omp_index, inter_mode)
@@ -98,18 +103,28 @@ class PostProcess(torch.nn.Module):
         """Asynchronous generate_poses: returns a PendingPoses; call .result() later.  Lets the
         caller queue the next batch's backbone before blocking on this batch's poses."""
         limbs = self.generate_limbs(features, flip_test, cat_flip_offs, scored_off)
-        poses, meta = self.limb_group.group_device(limbs)
-        slot = self._pinned.get(tuple(poses.shape))
-        if slot is None:
-            slot = [[torch.empty(poses.shape, dtype=torch.float32).pin_memory(),
-                     torch.empty(meta.shape, dtype=torch.int32).pin_memory()] for _ in range(2)]
-            self._pinned[tuple(poses.shape)] = slot
-        self._flip = 1 - self._flip
-        host_poses, host_meta = slot[self._flip]
-        host_poses.copy_(poses, non_blocking=True)
-        host_meta.copy_(meta, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record(torch.cuda.current_stream(poses.device))
+        dev = limbs.device
+        cur = torch.cuda.current_stream(dev)
+        stream = cur
+        if self.group_on_side_stream:
+            stream = self._side.get(dev.index)
+            if stream is None:
+                stream = self._side[dev.index] = torch.cuda.Stream(dev)
+            stream.wait_stream(cur)
+            limbs.record_stream(stream)
+        with torch.cuda.stream(stream):
+            poses, meta = self.limb_group.group_device(limbs)
+            slot = self._pinned.get(tuple(poses.shape))
+            if slot is None:
+                slot = [[torch.empty(poses.shape, dtype=torch.float32).pin_memory(),
+                         torch.empty(meta.shape, dtype=torch.int32).pin_memory()] for _ in range(2)]
+                self._pinned[tuple(poses.shape)] = slot
+            self._flip = 1 - self._flip
+            host_poses, host_meta = slot[self._flip]
+            host_poses.copy_(poses, non_blocking=True)
+            host_meta.copy_(meta, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(stream)
         return PendingPoses(self, limbs, poses, meta, host_poses, host_meta, event)
 
     def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
