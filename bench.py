@@ -173,6 +173,28 @@ def main():
     dec_fused_ms = timed(lambda i: proc.limb_group.group_device(proc.generate_limbs(fixed[i % n_rot], flip_test=a.flip)), 20)
     proc.fused_upsample = False
 
+    # C1, the dominant backbone kernel (13 of the 3x3 convolutions, 54 % of the network's FLOPs): the 160x160 256->256
+    # layer through og_conv3x3_bf16, bias + residual + ReLU epilogue included, HIP events around back-to-back launches
+    # on rotating activations (the network hands it activations the previous layer just wrote)
+    conv_us = conv_flop = None
+    if a.size == 640:
+        lib = _lib.load()
+        cl = torch.channels_last
+        nb_ = nb
+        xs = [torch.randn(nb_, 256, 160, 160, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(3)]
+        wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(torch.bfloat16).contiguous(memory_format=cl)
+        cb = torch.zeros(256, device=dev)
+        cws = torch.zeros(max(lib.og_conv3x3_workspace_bytes(nb_ * 160 * 160, 256, 256), 256), dtype=torch.uint8, device=dev)
+
+        def conv_once(i):
+            _lib.check(lib.og_conv3x3_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(wt), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
+                                           _lib.ptr(xs[(i + 2) % 3]), nb_, 160, 160, 256, 256, 1, _lib.ptr(cws), cws.numel(),
+                                           _lib.stream_ptr(dev)), lib)
+        timed(conv_once, 5)
+        conv_us = timed(conv_once, 30) * 1e3
+        conv_flop = 2.0 * nb_ * 160 * 160 * 256 * 2304
+        del xs
+
     # K1 on HBM-cold inputs: rotate hi-res heatmap batches whose total exceeds the 256 MiB Infinity Cache
     hr = [decoder.factory.upsample4(m[0][:a.batch], 'bicubic') for m in maps]
     _lib.profile_start()
@@ -213,6 +235,12 @@ def main():
                          'hbm_cold': {'us_per_launch': round(k1_cold, 2),
                                       'achieved': round(k1_bytes / (k1_cold * 1e-6) / 1e9, 1),
                                       'frac': round(k1_bytes / (k1_cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}},
+            'roofline_conv3x3': None if conv_us is None else {
+                'kernel': 'C1 = og_conv3x3_bf16 (conv3x3_halo_kernel<16,16,4>) on the 160x160 256->256 layer, epilogue fused',
+                'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
+                'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
+                'frac': round(conv_flop / (conv_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                'algorithmic_flop_per_launch': conv_flop},
             'roofline_backbone': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS,
                                   'achieved': round(nb * FLOP_PER_IMAGE / (bb_ms * 1e-3) / 1e12, 1),
                                   'frac': round(nb * FLOP_PER_IMAGE / (bb_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
