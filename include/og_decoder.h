@@ -172,6 +172,21 @@ int og_focal_l2_loss_f32(const float *pred, const float *gt, const unsigned char
 int og_offset_l1_loss_f32(const float *pred, const float *gt, const float *gt_ps, const unsigned char *mask_miss, int N,
                           int C, long hw, float margin, int sqrt_re, float *sum_count, float *grad, void *stream);
 
+/* ---- ground-truth encoder ----
+ * joints (N,P,n_kp,4) fp32 rows [x, y, v, scale] in input-image pixels (transforms/annotations.py:46-50), P = padded
+ * person count, n_persons int32[N] (NULL: all P rows are used; rows with v <= 0 never contribute).
+ * og_encode_heatmaps_f32: HeatMapGenerator.create_heatmaps encoder/heatmap.py:125-197 -> hm (N,n_kp,h,w) and, if not
+ *   NULL, bg (N,1,h,w) = 1 - max over channels (:78); h = in_h/stride, w = in_w/stride.
+ * og_encode_offsets_f32: OffsetMapGenerator.create_offsetmaps encoder/offset.py:98-197 -> off (N,2L,h,w) (inf where no
+ *   limb is defined), pscale (N,2L,h,w) (1 there), and, if not NULL, scale (N,n_kp,h,w) (nan there); jf/jt int32[L],
+ *   sigmas fp32[n_kp] (config COCO_PERSON_SIGMAS) are device arrays.
+ * Offsets/scales bit-exact vs the reference; heatmaps to ~2e-7 (device exp). */
+int og_encode_heatmaps_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, int in_w, int in_h,
+                           int stride, int sigma, float clip_thre, float *hm, float *bg, void *stream);
+int og_encode_offsets_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, const int32_t *jf,
+                          const int32_t *jt, int L, int in_w, int in_h, int stride, int fill_size, float min_jscale,
+                          const float *sigmas, float *off, float *scale, float *pscale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

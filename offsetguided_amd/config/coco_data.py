@@ -41,6 +41,10 @@ KINEMATIC_TREE_SKELETON = _pairs([
     5, 11, 11, 13, 13, 15, 6, 12, 12, 14, 14, 16])
 
 
+# per-keypoint OKS sigmas (config/coco_data.py:79-97): nose, eyes, ears, shoulders, elbows, wrists, hips, knees, ankles
+COCO_PERSON_SIGMAS = [0.026] + [s for s in (0.025, 0.035, 0.079, 0.072, 0.062, 0.107, 0.087, 0.089) for _ in (0, 1)]
+
+
 def heatmap_hflip(keypoints, hflip=None):
     """Channel permutation that maps a mirrored heatmap stack back (kp i <- kp perm[i])."""
     table = HFLIP if hflip is None else hflip

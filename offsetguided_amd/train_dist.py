@@ -19,7 +19,8 @@ import time
 import numpy as np
 import torch
 
-from . import models, sharding, synth
+from . import encoder, models, sharding, synth
+from .config import coco_data as cd
 from .utils import AverageMeter, adjust_learning_rate
 
 
@@ -54,6 +55,29 @@ def synthetic_targets(seed, batch, size, device):
     mask = torch.ones(batch, 1, h, h, dtype=torch.bool, device=device)
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     return [(t(np.clip(hm, 0, 1)), None, None, mask), (t(off), None, t(ps), mask)]
+
+
+def synthetic_annotations(seed, batch, size):
+    """Annotation-style input of the encoders: joints (N,P,17,4) fp32 [x, y, v, scale] padded to P persons, and the
+    person count per image (transforms/annotations.py:46-50 layout; the scale column plays the keypoint scale)."""
+    scenes = [synth.make_scene(synth.HashRng(seed * 1000003 + i), size, size) for i in range(batch)]
+    p_max = max(xy.shape[0] for xy, _, _ in scenes)
+    joints = np.zeros((batch, p_max, 17, 4), np.float32)
+    for i, (xy, vis, _) in enumerate(scenes):
+        p = xy.shape[0]
+        joints[i, :p, :, :2] = xy
+        joints[i, :p, :, 2] = vis * 2.0
+        extent = (xy[..., 1].max(1) - xy[..., 1].min(1)).astype(np.float32)            # person height in pixels
+        joints[i, :p, :, 3] = (extent[:, None] * np.asarray(cd.COCO_PERSON_SIGMAS, np.float32)[None]).astype(np.float32)
+    return joints, np.array([xy.shape[0] for xy, _, _ in scenes], np.int32)
+
+
+def encode_targets(encoders, joints, n_persons):
+    """Device-side ground truth (offsetguided_amd.encoder = reference encoder/): the same annos layout as
+    synthetic_targets, produced from annotations by the HIP encoder kernels inside the step."""
+    hm, bg, _, mask = encoders[0].encode_batch(joints, n_persons)
+    off, sc, ps, _ = encoders[1].encode_batch(joints, n_persons)
+    return [(hm, bg if bg.numel() else None, None, mask), (off, sc if sc.numel() else None, ps, mask)]
 
 
 def train_step(model, criterion, optimizer, images, annos, lambdas, autocast_dtype=torch.bfloat16):
@@ -102,18 +126,30 @@ def main(argv=None):
     os.makedirs(args.checkpoint_path, exist_ok=True)
     # a small rotating pool of synthetic batches per rank (generating targets on the host every step
     # would measure numpy, not the training step)
-    pool = []
+    # On the GPU the pool holds ANNOTATIONS and the targets are encoded on the device inside every step
+    # (the reference's numpy encoder manages 17 samples/s per dataloader worker, data/factory.py:284).
+    pool, encoders = [], None
+    if use_cuda:
+        encoder.HeatMaps.include_jitter_offset = False
+        encoder.HeatMaps.include_background = False
+        encoder.OffsetMaps.include_scale = False
+        encoders = encoder.factory_heads(['hmp', 'omp'], args.square_length, [4, 4], dev)
     for i in range(4):
         imgs = torch.randn(args.batch_size, 3, args.square_length, args.square_length, device=dev)
         if use_cuda:
             imgs = imgs.contiguous(memory_format=torch.channels_last)
-        pool.append((imgs, synthetic_targets(1000 * rank + i, args.batch_size, args.square_length, dev)))
+            joints, n_persons = synthetic_annotations(1000 * rank + i, args.batch_size, args.square_length)
+            pool.append((imgs, (torch.from_numpy(joints).to(dev), torch.from_numpy(n_persons).to(dev))))
+        else:
+            pool.append((imgs, synthetic_targets(1000 * rank + i, args.batch_size, args.square_length, dev)))
     for epoch in range(args.epochs):
         model.train()
         batch_time, losses, end = AverageMeter(), AverageMeter(), time.time()
         for step in range(args.steps_per_epoch):
             adjust_learning_rate(args.learning_rate, world, optimizer, epoch, step, args.steps_per_epoch, args.warmup)
             images, annos = pool[step % len(pool)]
+            if encoders is not None:
+                annos = encode_targets(encoders, *annos)
             loss, _ = train_step(model, criterion, optimizer, images, annos, args.lambdas,
                                  torch.bfloat16 if use_cuda else None)
             if step % args.print_freq == 0:

@@ -610,3 +610,96 @@ OGO_API void ogo_flip_cat(const float *hm, const float *off, int N, int C, int L
 }
 
 OGO_API int ogo_version(void) { return 1; }
+
+/* ===================================================================================================
+ * Ground-truth encoder: encoder/heatmap.py:125-197 and encoder/offset.py:98-197.
+ * joints (P,17,4) fp32 rows [x, y, v, scale] in input-image pixels (transforms/annotations.py:46-50).
+ * All arithmetic is fp32 as in the reference (numpy float32 arrays with weak Python scalars); Python's round()
+ * on an np.float32 is round-half-even = rintf.
+ * =================================================================================================== */
+static int ogo_patch(float c, int stride, float size, int *lo, int *hi)
+{
+    /* x_min = int(round(c / stride - size / 2)), x_max = int(round(c / stride + size / 2)); negative max: skipped;
+     * negative min: clamped (encoder/heatmap.py:154-171) */
+    float q = c / (float)stride, half = size / 2.f;
+    *lo = (int)rintf(q - half);
+    *hi = (int)rintf(q + half);
+    if (*hi < 0) return 0;
+    if (*lo < 0) *lo = 0;
+    return 1;
+}
+
+/* encoder/heatmap.py:141-197 (create_heatmaps / put_gaussian_peaks): hm (n_kp, h, w), max over the persons of the
+ * separable Gaussian exp_y[y]*exp_x[x] clipped below clip_thre, inside each person's window only. */
+OGO_API void ogo_encode_heatmaps(const float *joints, int P, int n_kp, int in_w, int in_h, int stride, int sigma,
+                                 float clip_thre, float *hm)
+{
+    const int w = in_w / stride, h = in_h / stride;
+    const double ds2 = 2.0 * sigma * sigma;
+    const int gsize = 2 * (int)ceil(sqrt(-ds2 * log((double)clip_thre)) / stride); /* heatmap.py:110-111 */
+    const float ds2f = (float)ds2;
+    memset(hm, 0, sizeof(float) * (size_t)n_kp * h * w);
+    for (int c = 0; c < n_kp; ++c)
+        for (int p = 0; p < P; ++p) {
+            const float *j = joints + ((size_t)p * n_kp + c) * 4;
+            if (!(j[2] > 0)) continue;
+            int x0, x1, y0, y1;
+            if (!ogo_patch(j[1], stride, (float)gsize, &y0, &y1)) continue; /* y_max < 0 is tested first (:159) */
+            if (!ogo_patch(j[0], stride, (float)gsize, &x0, &x1)) continue;
+            if (x1 > w) x1 = w; /* slices crop at the array border */
+            if (y1 > h) y1 = h;
+            for (int y = y0; y < y1; ++y) {
+                const float gy = (float)(y * stride + stride / 2.0 - 0.5), dy = gy - j[1];
+                const float ey = expf(-(dy * dy) / ds2f);
+                for (int x = x0; x < x1; ++x) {
+                    const float gx = (float)(x * stride + stride / 2.0 - 0.5), dx = gx - j[0];
+                    const float ex = expf(-(dx * dx) / ds2f);
+                    float e = ey * ex;
+                    if (e < clip_thre) e = 0.f;
+                    float *o = hm + ((size_t)c * h + y) * w + x;
+                    if (e > *o) *o = e;
+                }
+            }
+        }
+}
+
+/* encoder/offset.py:98-197 (create_offsetmaps / put_guide_offsets): per limb (fr, to) and person with both joints
+ * annotated, a fill_size window round the from-joint holds the vector to the to-joint; where windows overlap the
+ * shorter vector wins (strict <: the earlier person keeps ties).  off (2L,h,w) init inf, scale (n_kp,h,w) init nan,
+ * pscale (2L,h,w) init 1. */
+OGO_API void ogo_encode_offsets(const float *joints, int P, int n_kp, const int *jf, const int *jt, int L, int in_w,
+                                int in_h, int stride, int fill_size, float min_jscale, const float *sigmas,
+                                float *off, float *scale, float *pscale)
+{
+    const int w = in_w / stride, h = in_h / stride;
+    const size_t hw = (size_t)h * w;
+    for (size_t i = 0; i < 2 * L * hw; ++i) { off[i] = INFINITY; pscale[i] = 1.f; }
+    for (size_t i = 0; i < n_kp * hw; ++i) scale[i] = NAN;
+    for (int l = 0; l < L; ++l)
+        for (int p = 0; p < P; ++p) {
+            const float *j1 = joints + ((size_t)p * n_kp + jf[l]) * 4, *j2 = joints + ((size_t)p * n_kp + jt[l]) * 4;
+            if (!(j1[2] > 0 && j2[2] > 0)) continue;
+            int x0, x1, y0, y1;
+            if (!ogo_patch(j1[1], stride, (float)fill_size, &y0, &y1)) continue;
+            if (!ogo_patch(j1[0], stride, (float)fill_size, &x0, &x1)) continue;
+            if (x1 > w) x1 = w;
+            if (y1 > h) y1 = h;
+            for (int y = y0; y < y1; ++y) {
+                const float oy = j2[1] - (float)(y * stride + stride / 2.0 - 0.5);
+                for (int x = x0; x < x1; ++x) {
+                    const float ox = j2[0] - (float)(x * stride + stride / 2.0 - 0.5);
+                    const float len = sqrtf(ox * ox + oy * oy); /* np.linalg.norm over 2 fp32 elements */
+                    float *px = off + ((size_t)(2 * l) * h + y) * w + x, *py = px + hw;
+                    const float cur = sqrtf(*px * *px + *py * *py);
+                    if (len < cur) {
+                        *px = ox;
+                        *py = oy;
+                        scale[((size_t)jf[l] * h + y) * w + x] = j1[3] >= min_jscale ? j1[3] : NAN;
+                        const float ps = j1[3] / sigmas[jf[l]];
+                        pscale[((size_t)(2 * l) * h + y) * w + x] = ps;
+                        pscale[((size_t)(2 * l + 1) * h + y) * w + x] = ps;
+                    }
+                }
+            }
+        }
+}

@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "libog_oracle.so")
 
 __all__ = [
     "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
-    "greedy_group", "group_stats", "flip_merge", "flip_cat", "decode",
+    "greedy_group", "group_stats", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "decode",
 ]
 
 _lib = None
@@ -54,6 +54,9 @@ def lib():
                                            _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
         L.ogo_flip_cat.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _I32, _I32, _I32, C.c_int, _F, _F]
+        L.ogo_encode_heatmaps.argtypes = [_F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _F]
+        L.ogo_encode_offsets.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, _F, _F, _F, _F]
         L.ogo_greedy_group.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_double, C.c_float,
                                        C.c_int, C.c_int, C.c_int, _F]
         L.ogo_greedy_group.restype = C.c_int
@@ -185,6 +188,30 @@ def flip_cat(hm, off, kp_perm, limb_perm, reserve):
     lib().ogo_flip_cat(hm, off, n, c, L, h, w, np.array(kp_perm, np.int32), np.array(limb_perm, np.int32),
                        res if len(res) else np.zeros(1, np.int32), len(reserve), ho, oo)
     return ho, oo
+
+
+def encode_heatmaps(joints, in_w, in_h, stride=4, sigma=7, clip_thre=0.01):
+    """encoder/heatmap.py:125-197: joints (P,17,4) fp32 -> (17, h, w) Gaussian heatmaps."""
+    joints = _f32(joints)
+    p, n_kp = joints.shape[:2]
+    hm = np.empty((n_kp, in_h // stride, in_w // stride), np.float32)
+    lib().ogo_encode_heatmaps(joints, p, n_kp, in_w, in_h, stride, sigma, clip_thre, hm)
+    return hm
+
+
+def encode_offsets(joints, skeleton, sigmas, in_w, in_h, stride=4, fill_size=7, min_jscale=1.0):
+    """encoder/offset.py:98-197: -> offsets (2L,h,w) inf outside, keypoint scales (17,h,w) nan outside, person scales
+    (2L,h,w) 1 outside."""
+    joints = _f32(joints)
+    p, n_kp = joints.shape[:2]
+    jf = np.array([a for a, _ in skeleton], np.int32)
+    jt = np.array([b for _, b in skeleton], np.int32)
+    L = len(skeleton)
+    h, w = in_h // stride, in_w // stride
+    off, sc, ps = np.empty((2 * L, h, w), np.float32), np.empty((n_kp, h, w), np.float32), np.empty((2 * L, h, w), np.float32)
+    lib().ogo_encode_offsets(joints, p, n_kp, jf, jt, L, in_w, in_h, stride, fill_size, min_jscale,
+                             np.asarray(sigmas, np.float32), off, sc, ps)
+    return off, sc, ps
 
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -94,3 +95,23 @@ def test_ddp_step_keeps_replicas_in_sync_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
+
+
+@pytest.mark.gpu
+def test_gpu_train_steps_with_device_encoder(tmp_path):
+    """train_dist.main on the GPU: annotations -> HIP encoder -> fused HIP losses -> optimizer, a few steps."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    from offsetguided_amd import encoder, train_dist
+    joints, n_persons = train_dist.synthetic_annotations(3, 2, 256)
+    encoder.HeatMaps.include_jitter_offset = False
+    encoder.HeatMaps.include_background = False
+    encoder.OffsetMaps.include_scale = False
+    encs = encoder.factory_heads(['hmp', 'omp'], 256, [4, 4], 'cuda:0')
+    annos = train_dist.encode_targets(encs, torch.from_numpy(joints).cuda(), torch.from_numpy(n_persons).cuda())
+    hm, off, ps = annos[0][0], annos[1][0], annos[1][2]
+    assert hm.shape == (2, 17, 64, 64) and 0.9 < float(hm.max()) <= 1.0 and off.shape == (2, 38, 64, 64)
+    assert bool(torch.isfinite(off).any()) and bool(torch.isinf(off).any()) and float(ps.min()) >= 1.0
+    train_dist.main(['--no-pretrain', '--square-length', '256', '--batch-size', '2', '--epochs', '1', '--steps-per-epoch', '3',
+                     '--print-freq', '1', '--checkpoint-path', str(tmp_path)])
