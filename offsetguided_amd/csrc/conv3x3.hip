@@ -571,8 +571,11 @@ bool make_plan(long M, int Cin, int Cout, Plan &p)
     if (force_stages == 4 || (force_stages == 3 && bm == 128) || (force_stages == 8 && bm == 64)) p.stages = force_stages;
     p.m_tiles = (int)((M + bm - 1) / bm);
     p.n_tiles = Cout / bm;
+    // per layer inside the network (rocprofv3, conv + finish, us): 20x20 ks 2/3/6/9 = 34.9/31.4/36.2/41.1,
+    // 10x10 = 19.5/16.2/15.6/18.5, 5x5 = 22.5/17.4/12.7/12.7
+    const int max_ks = M >= 2048 ? 3 : 6;
     int best = 1;
-    for (int ks = 2; ks <= 6; ++ks)
+    for (int ks = 2; ks <= max_ks; ++ks)
         if (steps % ks == 0 && steps / ks >= 4 && steps / ks >= p.stages - 1) best = ks;
     if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
     if (steps < p.stages - 1) return false;
