@@ -581,9 +581,10 @@ bool make_plan(long M, int Cin, int Cout, Plan &p)
     if (steps < p.stages - 1) return false;
     p.ksplit = best;
     p.steps_per_split = steps / best;
-    // In-launch reduction saves a launch but pays one memory round trip per slab batch in the last arriver; measured
-    // inside the network it wins for the 5x5 level only (13.3 vs 14.9 us) and loses at 20x20 (39.9 vs 34.2 us).
-    p.in_launch = M <= 512;
+    // In-launch reduction (last arriver, one batch of sc1 loads) vs a finish kernel, per layer inside the network:
+    // 20x20 30.1 vs 32.0 us, 10x10 14.4 vs 15.9, 5x5 13.4 vs 13.1.  (With 128-wide tiles and 6 splits the in-launch
+    // form lost at 20x20, 39.9 vs 34.2: slab bytes per last arriver decide.)
+    p.in_launch = 1;
     if (const char *r = getenv("OG_CONV_REDUCE")) p.in_launch = atoi(r);
     return true;
 }
