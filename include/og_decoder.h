@@ -105,6 +105,15 @@ int og_collect_limbs_nd_f32(const float *scores, const int64_t *inds, const floa
                             int vector_nd, int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L,
                             int k, float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
 
+/* Same with the keypoint-scale head (decoder/collect.py:111-122, :257-262): limbs columns 11 / 12 = the scale map of
+ * the from / to joint channel at the from-peak / the matched to-peak instead of the constant 4.
+ * scales_mode 0: no head (scales NULL); 1: scales (N,C,H,W) at input resolution, gathered; 2 / 3: scales (N,C,H/4,W/4)
+ * = the head output, sampled as F.interpolate(x4, 'bicubic' / 'bilinear') would (decoder/factory.py:80-82). */
+int og_collect_limbs_ex_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                            int vector_nd, const float *scales, int scales_mode, int N, int C, int H, int W,
+                            const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
+                            float resize_factor, float *limbs, void *stream);
+
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,
  * decoder/factory.py:91-94).

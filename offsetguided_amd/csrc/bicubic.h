@@ -37,3 +37,18 @@ __device__ __forceinline__ OgRow4 og_cubic_xpass(float c0, const float (*wx)[4])
     o.p[3] = og_cubic_chain(cm1, c0, cp1, cp2, wx[3]);
     return o;
 }
+
+// one hi-res pixel of the x4 bicubic upsample of a low-res plane (same rounding as K1a)
+__device__ __forceinline__ float og_bicubic4_at(const float *__restrict__ lr, int h, int w, int Y, int X)
+{
+    const int qy = Y >> 2, ry = Y & 3, by = (ry < 2) ? qy - 1 : qy;
+    const int qx = X >> 2, rx = X & 3, bx = (rx < 2) ? qx - 1 : qx;
+    float rowv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *r = lr + (size_t)min(max(by - 1 + j, 0), h - 1) * w;
+        rowv[j] = og_cubic_chain(r[min(max(bx - 1, 0), w - 1)], r[min(max(bx, 0), w - 1)], r[min(max(bx + 1, 0), w - 1)],
+                                 r[min(max(bx + 2, 0), w - 1)], og_cubic_w[rx]);
+    }
+    return og_cubic_chain(rowv[0], rowv[1], rowv[2], rowv[3], og_cubic_w[ry]);
+}

@@ -15,6 +15,7 @@
 // exp() is the device libm (<= 1 ulp from torch's), so limb scores agree to ~1e-7 relative.
 #include <math.h>
 
+#include "bicubic.h"
 #include "og_common.h"
 
 namespace {
@@ -45,13 +46,23 @@ __global__ void __launch_bounds__(64)
 collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict__ inds,
                      const float *__restrict__ offs, int off_lowres, int C, int H, int W,
                      const int32_t *__restrict__ jf, const int32_t *__restrict__ jt, int L, int K,
-                     float thre, float min_len, float resize, float *__restrict__ limbs)
+                     float thre, float min_len, float resize, const float *__restrict__ scales, int scale_mode,
+                     float *__restrict__ limbs)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Kp = (K + 3) & ~3;                 // to-candidate coordinates interleaved (x,y), padded to 4
     float2 *txy = reinterpret_cast<float2 *>(sm);
     float *ts = sm + 2 * Kp;
     int *ti = reinterpret_cast<int *>(sm + 3 * Kp);
+    // keypoint-scale head (collect.py:111-122): the scale map of the joint's channel at the candidate's pixel;
+    // mode 1 = hi-res map gathered, 2 / 3 = stride-4 map sampled as F.interpolate(x4, bicubic / bilinear) would
+    auto scale_at = [&](int ch, long id, int yy, int xx) -> float {
+        if (scale_mode == 0) return 4.f;
+        const int n_ = blockIdx.x / L;
+        if (scale_mode == 1) return scales[((size_t)n_ * C + ch) * ((long)H * W) + id];
+        const float *pl = scales + ((size_t)n_ * C + ch) * (H / 4) * (W / 4);
+        return scale_mode == 2 ? og_bicubic4_at(pl, H / 4, W / 4, yy, xx) : bilinear4_at(pl, H / 4, W / 4, yy, xx);
+    };
     const int n = blockIdx.x / L, l = blockIdx.x % L, lane = threadIdx.x;
     const int cf = jf[l], ct = jt[l];
     const long HW = (long)H * W;
@@ -112,6 +123,8 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
             }
         }
         const float x2 = txy[best].x, y2 = txy[best].y, s2 = ts[best];
+        const int id2 = ti[best];
+        const float sc1 = scale_at(cf, id, yi, xi), sc2 = scale_at(ct, id2, id2 / W, id2 % W);
         const float lx = xf - x2, ly = yf - y2;
         float len = sqrtf(__builtin_fmaf(ly, ly, lx * lx));
         len = len < min_len ? min_len : len;                        // collect.py:204-205
@@ -121,7 +134,7 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
         o[3] = x2; o[4] = y2; o[5] = s2;
         o[6] = (float)(id + (int64_t)cf * HW);                       // collect.py:194-199, :227-228
         o[7] = (float)((int64_t)ti[best] + (int64_t)ct * HW);
-        o[8] = bd; o[9] = len; o[10] = sc; o[11] = 4.f; o[12] = 4.f;
+        o[8] = bd; o[9] = len; o[10] = sc; o[11] = sc1; o[12] = sc2;
     }
 }
 
@@ -139,7 +152,19 @@ OG_API int og_collect_limbs_nd_f32(const float *scores, const int64_t *inds, con
                                    int vector_nd, int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L,
                                    int k, float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream)
 {
-    const char *name = "og_collect_limbs_nd_f32";
+    return og_collect_limbs_ex_f32(scores, inds, offs, off_is_lowres, vector_nd, nullptr, 0, N, C, H, W, jf, jt, L, k,
+                                   thre_hmp, min_len, resize_factor, limbs, stream);
+}
+
+OG_API int og_collect_limbs_ex_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                                   int vector_nd, const float *scales, int scales_mode, int N, int C, int H, int W,
+                                   const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
+                                   float resize_factor, float *limbs, void *stream)
+{
+    const char *name = "og_collect_limbs_ex_f32";
+    OG_REQUIRE(scales_mode >= 0 && scales_mode <= 3 && (scales_mode == 0) == (scales == nullptr), OG_EINVAL,
+               "%s: scales_mode 0 (no scale head) .. 3, with a map exactly when it is not 0", name);
+    OG_REQUIRE(scales_mode < 2 || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
     OG_REQUIRE(vector_nd == 2 || vector_nd == 4, OG_EUNSUPPORTED, "%s: vector_nd must be 2 or 4", name);
     OG_REQUIRE(scores && inds && offs && jf && jt && limbs, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && L > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
@@ -148,7 +173,7 @@ OG_API int og_collect_limbs_nd_f32(const float *scores, const int64_t *inds, con
     OG_REQUIRE(k <= 2048, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
     auto kern = vector_nd == 2 ? collect_limbs_kernel<2> : collect_limbs_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(N * L), dim3(64), (size_t)((k + 3) & ~3) * 16, (hipStream_t)stream, scores, inds, offs,
-                       off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs);
+                       off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode, limbs);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -525,21 +525,6 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 //   B) compact the keys >= L (usually just over k of them);
 //   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
-// one hi-res pixel of the x4 bicubic upsample of a low-res plane (same rounding as K1a)
-__device__ __forceinline__ float bicubic4_at(const float *__restrict__ lr, int h, int w, int Y, int X)
-{
-    const int qy = Y >> 2, ry = Y & 3, by = (ry < 2) ? qy - 1 : qy;
-    const int qx = X >> 2, rx = X & 3, bx = (rx < 2) ? qx - 1 : qx;
-    float rowv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float *r = lr + (size_t)min(max(by - 1 + j, 0), h - 1) * w;
-        rowv[j] = og_cubic_chain(r[min(max(bx - 1, 0), w - 1)], r[min(max(bx, 0), w - 1)], r[min(max(bx + 1, 0), w - 1)],
-                                 r[min(max(bx + 2, 0), w - 1)], og_cubic_w[rx]);
-    }
-    return og_cubic_chain(rowv[0], rowv[1], rowv[2], rowv[3], og_cubic_w[ry]);
-}
-
 template <bool NMS_MODE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
@@ -601,7 +586,7 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
         const float *p = in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W);
-        auto px = [&](int yy, int xx) { return FUSED ? bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
+        auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
         const long hw = (long)H * W;
         for (long base = 0; base < hw && t < k; base += 64) {
             const long i = base + lane;

@@ -242,9 +242,23 @@ OGO_API void ogo_collect_limbs(const float *scores, const int64_t *inds, const f
     ogo_collect_limbs_nd(scores, inds, offs, off_lowres, N, C, H, W, jf, jt, L, K, thre, min_len, resize, 2, limbs);
 }
 
+/* scales_hr (N,C,H,W) or NULL: the keypoint-scale head brought to input resolution by F.interpolate(mode=inter_mode)
+ * (decoder/factory.py:80-82); limbs columns 11 / 12 = its value in the from / to joint channel at the from-peak / the
+ * matched to-peak (decoder/collect.py:111-122, :257-262), the constant 4 without the head. */
+OGO_API void ogo_collect_limbs_ex(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                  const float *scales_hr, int N, int C, int H, int W, const int *jf, const int *jt, int L,
+                                  int K, float thre, float min_len, float resize, int vector_nd, float *limbs);
+
 OGO_API void ogo_collect_limbs_nd(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
                                   int N, int C, int H, int W, const int *jf, const int *jt, int L, int K,
                                   float thre, float min_len, float resize, int vector_nd, float *limbs)
+{
+    ogo_collect_limbs_ex(scores, inds, offs, off_lowres, NULL, N, C, H, W, jf, jt, L, K, thre, min_len, resize, vector_nd, limbs);
+}
+
+OGO_API void ogo_collect_limbs_ex(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                  const float *scales_hr, int N, int C, int H, int W, const int *jf, const int *jt, int L,
+                                  int K, float thre, float min_len, float resize, int vector_nd, float *limbs)
 {
     const int nd = vector_nd;
     const long HW = (long)H * W;
@@ -300,7 +314,9 @@ OGO_API void ogo_collect_limbs_nd(const float *scores, const int64_t *inds, cons
                 o[3] = tx[best]; o[4] = ty[best]; o[5] = st[best];
                 o[6] = (float)(idf[k] + (int64_t)jf[l] * HW);
                 o[7] = (float)(idt[best] + (int64_t)jt[l] * HW);
-                o[8] = bd; o[9] = len; o[10] = sc; o[11] = 4.f; o[12] = 4.f;
+                o[8] = bd; o[9] = len; o[10] = sc;
+                o[11] = scales_hr ? scales_hr[((size_t)n * C + jf[l]) * HW + idf[k]] : 4.f;
+                o[12] = scales_hr ? scales_hr[((size_t)n * C + jt[l]) * HW + idt[best]] : 4.f;
             }
         }
     free(tx);

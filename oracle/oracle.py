@@ -52,6 +52,8 @@ def lib():
                                         _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F]
         L.ogo_collect_limbs_nd.argtypes = [_F, _I64, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
+        L.ogo_collect_limbs_ex.argtypes = [_F, _I64, _F, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
         L.ogo_flip_cat.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _I32, _I32, _I32, C.c_int, _F, _F]
         L.ogo_encode_heatmaps.argtypes = [_F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _F]
@@ -120,7 +122,8 @@ def nms_topk(hm, k):
     return os_, oi, oi // w, oi % w
 
 
-def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0, vector_nd=2):
+def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0, vector_nd=2,
+                  scales_hr=None):
     """decoder/collect.py:62-236; `offs` low-res (bilinear-sampled) or hi-res (gathered); vector_nd=4 for the
     cat_flip_offs form (offs then has 4 components per limb)."""
     scores = _f32(scores)
@@ -132,7 +135,11 @@ def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_
     jt = np.array([b for _, b in skeleton], np.int32)
     L = len(skeleton)
     limbs = np.empty((n, L, k, 13), np.float32)
-    lib().ogo_collect_limbs_nd(scores, inds, offs, int(bool(off_lowres)), n, c, H, W, jf, jt, L, k,
+    if scales_hr is not None:
+        scales_hr = _f32(scales_hr)
+        assert scales_hr.shape == (n, c, H, W)
+    lib().ogo_collect_limbs_ex(scores, inds, offs, int(bool(off_lowres)),
+                               scales_hr.ctypes.data if scales_hr is not None else None, n, c, H, W, jf, jt, L, k,
                                thre, min_len, resize, int(vector_nd), limbs)
     return limbs
 
@@ -215,7 +222,8 @@ def encode_offsets(joints, skeleton, sigmas, in_w, in_h, stride=4, fill_size=7, 
 
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,
-           dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False, cat_flip_offs=False):
+           dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False, cat_flip_offs=False,
+           scales_lr=None):
     """PostProcess.generate_poses (decoder/factory.py:52-96) on low-res head outputs.
 
     flip = (kp_perm, limb_perm, reserve) enables the flip-test merge first.
@@ -227,12 +235,20 @@ def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, pe
         nd = 4
     elif flip is not None:
         hm_lr, off_lr = flip_merge(hm_lr, off_lr, *flip)
+    sc_hr = None
+    if scales_lr is not None:  # keypoint-scale head: flip-averaged like the heatmaps (factory.py:141-144), then x4 bicubic
+        scales_lr = _f32(scales_lr)
+        if flip is not None:
+            half = scales_lr.shape[0] // 2
+            scales_lr = (scales_lr[:half] + scales_lr[half:, list(flip[0])][..., ::-1]) / np.float32(2)
+        sc_hr = bicubic4(np.ascontiguousarray(scales_lr))
     hm_hr = bicubic4(hm_lr)
     n, c, H, W = hm_hr.shape
     sc, idx, _, _ = nms_topk(hm_hr, topk_k)
     if materialize_offsets:
-        limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd)
+        limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd,
+                              scales_hr=sc_hr)
     else:
-        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd)
+        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd, scales_hr=sc_hr)
     poses = [greedy_group(limbs[i], skeleton, c, person_thre, dist_max, use_scale, sort_dim) for i in range(n)]
     return poses, {"hm_hr": hm_hr, "scores": sc, "inds": idx, "limbs": limbs}

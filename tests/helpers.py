@@ -30,6 +30,15 @@ def is_cat(g):
     return bool(int(g["cat"])) if "cat" in g.files else False
 
 
+def scale_case_inputs(g):
+    """Inputs of a keypoint-scale-head fixture (tools/gen_golden.py:scale_case), sha-guarded."""
+    batch, size, flip, seed = int(g["batch"]), int(g["size"]), bool(g["flip"]), int(g["seed"])
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=8)
+    scl = (synth.noise_batch(seed + 5, (hm.shape[0], 17, size // 4, size // 4)) * 20 + 25).astype(np.float32)
+    assert [sha(hm), sha(off), sha(scl)] == list(g["in_sha"]), "synthetic input generator drifted (not a parity failure)"
+    return hm, off, scl
+
+
 def load_case(name):
     """Golden case + regenerated inputs (sha-guarded against generator drift)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))

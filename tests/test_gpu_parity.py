@@ -10,7 +10,7 @@ import torch
 import oracle
 from offsetguided_amd import _lib, decoder, synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, scale_case_inputs,
                      split_poses)
 
 pytestmark = pytest.mark.gpu
@@ -311,6 +311,36 @@ def test_generate_poses_golden(dev, name):
     poses = proc.generate_poses(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g))
     assert all(p.dtype == np.float32 for p in poses)
     assert_poses_match(split_poses(g), poses, SCORE_TOL)
+
+
+@pytest.mark.parametrize("name", ["scale256", "scale256_flip"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_scale_head_golden(dev, name, fused):
+    """include_scale / use_scale: scale maps sampled at the peaks from the stride-4 head output (K2), scale-dependent
+    rejection radius in K3; the poses' scale column is exact."""
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, scl = scale_case_inputs(g)
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    a = p.parse_args(['--topk', str(FLAGS['topk']), '--thre-hmp', str(FLAGS['thre_hmp']), '--person-thre',
+                      str(FLAGS['person_thre']), '--dist-max', '6', '--min-len', str(FLAGS['min_len']), '--use-scale', 'True'])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], int(g["batch"])
+    a.include_scale, a.include_jitter_offset = True, False
+    proc = decoder.decoder_factory(a)
+    proc.fused_upsample = fused
+    t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    feats = [([None, t(hm)], [[], []], [[], []]), ([None, t(off)], [[], []], [None, t(scl)])]
+    poses = proc.generate_poses(feats, flip_test=bool(g["flip"]))
+    assert_poses_match(split_poses(g), poses, SCORE_TOL)
+    for r, m in zip(split_poses(g), poses):
+        assert (r[..., 3] == m[..., 3]).all()
+    # the reference's own LimbsCollect call on maps at input resolution gathers the same scales
+    if not bool(g["flip"]):
+        hr = decoder.factory.upsample4(t(hm), 'bicubic')
+        limbs_hr = proc.limb_collect.generate_limbs(hr, [], decoder.factory.upsample4(t(off), 'bilinear'),
+                                                    decoder.factory.upsample4(t(scl), 'bicubic')).cpu().numpy()
+        limbs_lr = proc.generate_limbs(feats).cpu().numpy()
+        assert (limbs_hr[..., 11:] == limbs_lr[..., 11:]).all()
 
 
 @pytest.mark.parametrize("size,batch,k,flip", [((384, 512), 3, 48, False), ((128, 640), 2, 16, True), ((512, 256), 1, 32, False)])

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from offsetguided_amd import synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, scale_case_inputs,
                      sha, split_poses)
 
 
@@ -73,3 +73,17 @@ def test_topk_tie_rule_and_errors():
     assert i.tolist() == [[[13, 0, 1, 2]]] and s.tolist() == [[[1.0, 0.0, 0.0, 0.0]]]
     with pytest.raises(RuntimeError):
         oracle.topk(z, 21)
+
+
+@pytest.mark.parametrize("name", ["scale256", "scale256_flip"])
+def test_scale_head_case(name):
+    """Keypoint-scale head (include_scale / use_scale): poses incl. the exact scale column vs the reference's."""
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, scl = scale_case_inputs(g)
+    flip = flip_tables() if int(g["flip"]) else None
+    poses, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                             min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=6.0, use_scale=True,
+                             flip=flip, scales_lr=scl)
+    assert_poses_match(split_poses(g), poses)
+    for r, m in zip(split_poses(g), poses):
+        assert (r[..., 3] == m[..., 3]).all()

@@ -158,6 +158,40 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
     print(f'{name}: poses/img {[len(p) for p in poses]}, all_pos={all_pos}, limb score err {ds:.2e}, pose ls err {dp:.2e}')
 
 
+def scale_case(decoder, name, seed, batch, size, flip):
+    """Keypoint-scale head (include_scale): scale maps ride in features[omp][2], LimbsCollect gathers them into limbs
+    columns 11/12 and GreedyGroup(use_scale=True) uses max(dist_max, scale_to) as the rejection radius."""
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=8)
+    nb = hm.shape[0]
+    scl = (synth.noise_batch(seed + 5, (nb, 17, size // 4, size // 4)) * 20 + 25).astype(np.float32)   # 5 .. 45 px
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    a = p.parse_args(['--topk', str(FLAGS['topk']), '--thre-hmp', str(FLAGS['thre_hmp']), '--person-thre',
+                      str(FLAGS['person_thre']), '--dist-max', '6', '--min-len', str(FLAGS['min_len']), '--use-scale', 'True'])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], batch
+    a.include_scale, a.include_jitter_offset = True, False
+    proc = decoder.decoder_factory(a)
+    t = torch.from_numpy
+    feats = [([t(hm) * 0, t(hm)], [[], []], [[], []]), ([t(off) * 0, t(off)], [[], []], [t(scl) * 0, t(scl)])]
+    poses = proc.generate_poses(feats, flip_test=flip)
+    proc.worker_pool.close()
+    fl = None
+    if flip:
+        perm, rev = offset_hflip(COCO_KEYPOINTS, COCO_PERSON_SKELETON)
+        fl = (heatmap_hflip(COCO_KEYPOINTS), perm, rev)
+    o_poses, o_mid = oracle.decode(hm, off, COCO_PERSON_SKELETON, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
+                                   min_len=FLAGS['min_len'], person_thre=FLAGS['person_thre'], dist_max=6.0,
+                                   use_scale=True, flip=fl, scales_lr=scl)
+    dp = check_poses(poses, o_poses, name)
+    # the scale columns of the poses come straight from the gathered maps: exact
+    for r, m in zip(poses, o_poses):
+        assert (r[..., 3] == m[..., 3]).all()
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), seed=seed, batch=batch, size=size, flip=int(flip),
+                        in_sha=np.array([sha(hm), sha(off), sha(scl)]), n_poses=np.array([len(q) for q in poses]),
+                        poses=np.concatenate(poses, 0) if sum(len(q) for q in poses) else np.zeros((0, 17, 6), np.float32))
+    print(f'{name}: poses/img {[len(q) for q in poses]} with the scale head, pose ls err {dp:.2e}')
+
+
 def adversarial_limbs(rng, K, hw=4096, skeleton=COCO_PERSON_SKELETON):
     """(19,K,13) limbs with many index collisions.
 
@@ -276,6 +310,8 @@ def main():
     decoder = load_reference()
     pipeline_case(decoder, 'pipe256_flipcat_p6', 306, 2, 256, True, 6, cat=True)
     pipeline_case(decoder, 'pipe640_flipcat', 642, 2, 640, True, None, cat=True)
+    scale_case(decoder, 'scale256', 401, 2, 256, False)
+    scale_case(decoder, 'scale256_flip', 402, 2, 256, True)
     if '--cat-only' in sys.argv:
         return
     stage_units()
