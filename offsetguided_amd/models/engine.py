@@ -211,6 +211,9 @@ class InferenceEngine:
         hm_head, off_head = dev_model.headnets[0], dev_model.headnets[1]
         self.hm = _Conv(hm_head.hp_convs[self.stage], None, False, dtype, False)
         self.off = _Conv(off_head.reg_convs[self.stage], None, False, dtype, False)
+        # optional keypoint-scale head (models/heads.py:112,136): third element of the offset head's output
+        self.scale = (_Conv(off_head.scale_convs[self.stage], None, False, dtype, False)
+                      if getattr(off_head, 'include_scale', False) else None)
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -227,6 +230,8 @@ class InferenceEngine:
                 inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
         hm = self.hm(feat).float().contiguous(memory_format=torch.contiguous_format)
         off = self.off(feat).float().contiguous(memory_format=torch.contiguous_format)
+        if self.scale is not None:
+            return hm, off, self.scale(feat).float().contiguous(memory_format=torch.contiguous_format)
         return hm, off
 
     def _capture(self):
@@ -247,7 +252,7 @@ class InferenceEngine:
 
     @torch.no_grad()
     def forward_raw(self, images):
-        """(hm (N,17,h,w), off (N,38,h,w)) fp32 NCHW; graph outputs are reused by the next call."""
+        """(hm (N,17,h,w), off (N,38,h,w)[, scale (N,17,h,w)]) fp32 NCHW; graph outputs are reused by the next call."""
         assert tuple(images.shape) == self.shape, f'engine built for {self.shape}, got {tuple(images.shape)}'
         if self._graph is None:
             return self._forward(images.to(self.device))
@@ -256,8 +261,12 @@ class InferenceEngine:
         return self._out
 
     def __call__(self, images):
-        hm, off = self.forward_raw(images)
+        hm, off, *scl = self.forward_raw(images)
         hms, offs = [None] * self.n_stacks, [None] * self.n_stacks
         hms[self.stage], offs[self.stage] = hm, off
         empty = [[] for _ in range(self.n_stacks)]
-        return [(hms, list(empty), list(empty)), (offs, list(empty), list(empty))]
+        scales = list(empty)
+        if scl:
+            scales = [None] * self.n_stacks
+            scales[self.stage] = scl[0]
+        return [(hms, list(empty), list(empty)), (offs, list(empty), scales)]

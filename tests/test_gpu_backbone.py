@@ -169,6 +169,23 @@ def test_engine_other_shapes_match_eager(dev, batch, height, width):
         assert torch.equal(o, out2[h][0][-1])
 
 
+def test_engine_scale_head(dev):
+    """A model built with the keypoint-scale head: the engine returns it as features[omp][2][stage]."""
+    import bench
+    p = argparse.ArgumentParser()
+    models.net_cli(p)
+    model, _ = models.model_factory(p.parse_args(['--no-pretrain', '--include-scale']))
+    bench.bench_init(model, 5)
+    x = torch.randn(1, 3, 128, 128, device=dev)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        ref = model(x)
+    out = models.InferenceEngine(model, 1, 128, 128, device=dev, use_graph=False)(x)
+    r, o = ref[1][2][-1].float(), out[1][2][-1]
+    assert o.shape == r.shape == (1, 17, 32, 32) and out[1][2][0] is None
+    assert (o - r).abs().max().item() <= 0.05 * r.abs().max().item()
+
+
 def test_engine_matches_reference_golden(dev):
     """The reference model's outputs on key-seeded weights (tests/golden/backbone128.npz, generated from the imported
     reference) vs the GPU engine: fp32 engine <= 1e-3 relative, bf16 engine reported and loosely gated."""
