@@ -322,9 +322,6 @@ conv3x3_kernel(ConvArgs a)
 //   loads are vector-memory ops: every one of them drained the DMA queue with vmcnt(0)).  9 is odd, so 16 pixels
 //   of a tile row land on 16 different 16-B bank slots; the k-chunk offset between the two halves of a
 //   ds_read_b128 lane group leaves a 2-way conflict on 7 of 16 slots.  The weight tile keeps the XOR swizzle.
-#ifndef HALO_EXP
-#define HALO_EXP 0
-#endif
 // TW x TH = pixel tile (TW*TH a multiple of 16*WM), WM = waves along the pixels (8/WM along the 128 couts).
 // A 16-pixel MFMA column block is 16 consecutive pixels of the tile in row-major order (it may wrap over tile rows:
 // only the per-lane base address knows), so TW need not be a multiple of 16: 16x16 tiles serve 160x160 / 80x80,
