@@ -313,6 +313,15 @@ def test_generate_poses_golden(dev, name):
     assert_poses_match(split_poses(g), poses, SCORE_TOL)
 
 
+def test_scored_offset_golden(dev):
+    """generate_poses(scored_off=True): heatmap-weighted offsets (torch ops on the device) feeding the HIP decoder."""
+    g = np.load(f"{GOLDEN}/scored256.npz")
+    hm, off = synth.synth_batch(int(g["seed"]), int(g["batch"]), int(g["size"]), int(g["size"]), n_persons=6)
+    proc = processor(int(g["batch"]))
+    poses = proc.generate_poses(features(hm, off, dev), scored_off=True)
+    assert_poses_match(split_poses(g), poses, SCORE_TOL)
+
+
 @pytest.mark.parametrize("name", ["scale256", "scale256_flip"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_scale_head_golden(dev, name, fused):

@@ -87,3 +87,19 @@ def test_scale_head_case(name):
     assert_poses_match(split_poses(g), poses)
     for r, m in zip(split_poses(g), poses):
         assert (r[..., 3] == m[..., 3]).all()
+
+
+def test_scored_offset_matches_reference_golden():
+    """decoder/offset.py:8-43 (optional, off by default): our torch formulation is bit-identical to the reference's on
+    the CPU (asserted at generation time and re-checked here through the stored hash); poses with scored_off=True."""
+    import torch
+    from offsetguided_amd.decoder.offset import pack_jtypes, scored_offset
+    g = np.load(f"{GOLDEN}/scored256.npz")
+    hm, off = synth.synth_batch(int(g["seed"]), int(g["batch"]), int(g["size"]), int(g["size"]), n_persons=6)
+    assert [sha(hm), sha(off)] == list(g["in_sha"])
+    jf, jt = pack_jtypes(cd.COCO_PERSON_SKELETON)
+    scored = scored_offset(torch.from_numpy(hm), torch.from_numpy(off), jf, jt, kernel_size=3).numpy()
+    assert sha(scored) == str(g["scored_sha"])
+    poses, _ = oracle.decode(hm, scored, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                             min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"])
+    assert_poses_match(split_poses(g), poses)

@@ -192,6 +192,27 @@ def scale_case(decoder, name, seed, batch, size, flip):
     print(f'{name}: poses/img {[len(q) for q in poses]} with the scale head, pose ls err {dp:.2e}')
 
 
+def scored_case(decoder):
+    """Optional heatmap-weighted offsets (decoder/offset.py:8-43, generate_poses(scored_off=True)): the function itself
+    (bit-exact: same torch ops) and the poses it leads to."""
+    from offsetguided_amd.decoder.offset import scored_offset as mine
+    hm, off = synth.synth_batch(501, 2, 256, 256, n_persons=6)
+    jf, jt = decoder.offset.pack_jtypes(COCO_PERSON_SKELETON)
+    ref = decoder.scored_offset(torch.from_numpy(hm), torch.from_numpy(off), jf, jt, kernel_size=3)
+    got = mine(torch.from_numpy(hm), torch.from_numpy(off), jf, jt, kernel_size=3)
+    assert torch.equal(ref, got), 'scored_offset differs from the reference'
+    proc = ref_processor(decoder, 2)
+    poses = proc.generate_poses(features(hm, off), scored_off=True)
+    proc.worker_pool.close()
+    o_poses, _ = oracle.decode(hm, ref.numpy(), COCO_PERSON_SKELETON, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
+                               min_len=FLAGS['min_len'], person_thre=FLAGS['person_thre'], dist_max=FLAGS['dist_max'])
+    dp = check_poses(poses, o_poses, 'scored256')
+    np.savez_compressed(os.path.join(GOLD, 'scored256.npz'), seed=501, batch=2, size=256, in_sha=np.array([sha(hm), sha(off)]),
+                        scored_sha=np.array(sha(ref.numpy())), n_poses=np.array([len(q) for q in poses]),
+                        poses=np.concatenate(poses, 0))
+    print(f'scored256: scored_offset bit-exact, poses/img {[len(q) for q in poses]}, pose ls err {dp:.2e}')
+
+
 def adversarial_limbs(rng, K, hw=4096, skeleton=COCO_PERSON_SKELETON):
     """(19,K,13) limbs with many index collisions.
 
@@ -310,6 +331,7 @@ def main():
     decoder = load_reference()
     pipeline_case(decoder, 'pipe256_flipcat_p6', 306, 2, 256, True, 6, cat=True)
     pipeline_case(decoder, 'pipe640_flipcat', 642, 2, 640, True, None, cat=True)
+    scored_case(decoder)
     scale_case(decoder, 'scale256', 401, 2, 256, False)
     scale_case(decoder, 'scale256_flip', 402, 2, 256, True)
     if '--cat-only' in sys.argv:
