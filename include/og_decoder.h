@@ -155,6 +155,15 @@ int og_flip_cat_f32(const float *hm, const float *off, int N, int C, int L, int 
 int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream);
 int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream);
 
+/* Engine boundary conversions (models/networks.py:189-194 hands fp32 NCHW in and out; the engine computes bf16 NHWC):
+ * og_nchw_f32_to_nhwc_bf16: images (N,3,H,W) fp32 -> (N,H,W,3) bf16, one pass.
+ * og_nhwc_bf16_to_nchw_f32: channels [first, first+channels) of src (N,H,W,src_channels) bf16, plus bias[first+c]
+ *   (fp32[src_channels] or NULL), -> dst (N,channels,H,W) fp32: the head maps of models/heads.py:48-70,116-142 out of
+ *   ONE 1x1 convolution that evaluates all heads. */
+int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, int H, int W, void *stream);
+int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
+                             float *dst, long N, int H, int W, void *stream);
+
 /* ---- 3x3 stride-1 pad-1 convolution with the epilogue fused, for the small inner hourglass levels ----
  * out = act(conv3x3(x, w) + bias (+ skip)):  convolution.forward models/hourglass_104.py:26-30 / residual.forward
  * :70-79 with BN folded.  x (N,H,W,Cin), w (Cout,3,3,Cin) [= channels_last (Cout,Cin,3,3)], skip/out (N,H,W,Cout),

@@ -40,6 +40,8 @@ SIGNATURES = {
     "og_flip_cat_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_bias_act_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "og_upsample2_add_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
+    "og_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
+    "og_nhwc_bf16_to_nchw_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _i, _i, _vp]),
     "og_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv3x3_workspace_bytes": (_sz, [_l, _i, _i]),
     "og_conv3x3_debug_stamps": (None, [_vp]),

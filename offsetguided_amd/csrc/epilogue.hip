@@ -108,3 +108,64 @@ OG_API int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
+
+// ---- layout/dtype conversions at the two ends of the engine -------------------------------------------------------
+// The reference interface hands the model fp32 NCHW images and expects fp32 NCHW head maps; the engine computes in
+// bf16 NHWC.  PyTorch does each conversion as a cast pass plus a layout pass; these do it in one.
+namespace {
+
+// images (N,C,H,W) fp32 -> (N,H,W,C) bf16; thread = pixel, C small (3)
+template <int C>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, long hw, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / hw, p = i % hw;
+    const float *s = src + n * C * hw + p;
+    unsigned short *d = dst + i * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = f2bf(s[(long)c * hw]);
+}
+
+// head maps: src (N,H,W,src_c) bf16, channels [c0, c0+C) (+ bias) -> dst (N,C,H,W) fp32; thread = pixel
+__global__ void __launch_bounds__(256)
+nhwc_slice_to_nchw_f32_kernel(const unsigned short *__restrict__ src, int src_c, int c0, int C,
+                              const float *__restrict__ bias, float *__restrict__ dst, long hw, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / hw, p = i % hw;
+    const unsigned short *s = src + i * src_c + c0;
+    float *d = dst + n * C * hw + p;
+    for (int c = 0; c < C; ++c) d[(long)c * hw] = bf2f(s[c]) + (bias ? bias[c0 + c] : 0.f);
+}
+
+}  // namespace
+
+OG_API int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, int H, int W, void *stream)
+{
+    const char *name = "og_nchw_f32_to_nhwc_bf16";
+    OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(C == 3, OG_EUNSUPPORTED, "%s: only 3-channel images", name);
+    const long hw = (long)H * W, total = N * hw;
+    hipLaunchKernelGGL((nchw_to_nhwc_bf16_kernel<3>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, (unsigned short *)dst, hw, total);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
+                                    float *dst, long N, int H, int W, void *stream)
+{
+    const char *name = "og_nhwc_bf16_to_nchw_f32";
+    OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0 && channels > 0 && first_channel >= 0 && first_channel + channels <= src_channels,
+               OG_EINVAL, "%s: bad shape", name);
+    const long hw = (long)H * W, total = N * hw;
+    hipLaunchKernelGGL(nhwc_slice_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)src, src_channels, first_channel, channels, bias, dst, hw, total);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

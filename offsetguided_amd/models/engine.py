@@ -214,6 +214,20 @@ class InferenceEngine:
         # optional keypoint-scale head (models/heads.py:112,136): third element of the offset head's output
         self.scale = (_Conv(off_head.scale_convs[self.stage], None, False, dtype, False)
                       if getattr(off_head, 'include_scale', False) else None)
+        # GPU bf16 path: all heads as ONE 1x1 convolution (output channels padded to a multiple of 8); the maps leave
+        # through og_nhwc_bf16_to_nchw_f32 (bias added in fp32, one pass) instead of bias / cast / layout passes each
+        self.heads_w = None
+        if fused:
+            parts = [h for h in (self.hm, self.off, self.scale) if h is not None]
+            self.head_channels = [h.w.shape[0] for h in parts]
+            w = torch.cat([h.w for h in parts], 0)
+            b = torch.cat([h.b32 for h in parts], 0)
+            pad = (-w.shape[0]) % 8
+            if pad:
+                w = torch.cat([w, torch.zeros((pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)], 0)
+                b = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
+            self.heads_w = w.contiguous(memory_format=torch.channels_last)
+            self.heads_b = b.contiguous()
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -221,13 +235,32 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
-        x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        if self.fused:   # fp32 NCHW -> bf16 NHWC in one pass
+            lib = _lib.load()
+            images = images.float().contiguous()
+            n, c, h, w = images.shape
+            x = torch.empty((n, c, h, w), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
+            _lib.check(lib.og_nchw_f32_to_nhwc_bf16(_lib.ptr(images), _lib.ptr(x), n, c, h, w, _lib.stream_ptr(images.device)), lib)
+        else:
+            x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
         inter = _run(self.pre, x)
         feat = None
         for s in range(self.stage + 1):
             feat = self.cnvs[s](self.kps[s](inter))
             if s < self.stage:
                 inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
+        if self.heads_w is not None:
+            lib = _lib.load()
+            y = F.conv2d(feat, self.heads_w)
+            n, cc, h, w = y.shape
+            outs, c0 = [], 0
+            for ch in self.head_channels:
+                o = torch.empty((n, ch, h, w), dtype=torch.float32, device=y.device)
+                _lib.check(lib.og_nhwc_bf16_to_nchw_f32(_lib.ptr(y), cc, c0, ch, _lib.ptr(self.heads_b), _lib.ptr(o), n, h, w,
+                                                        _lib.stream_ptr(y.device)), lib)
+                outs.append(o)
+                c0 += ch
+            return tuple(outs)
         hm = self.hm(feat).float().contiguous(memory_format=torch.contiguous_format)
         off = self.off(feat).float().contiguous(memory_format=torch.contiguous_format)
         if self.scale is not None:
