@@ -164,6 +164,13 @@ int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, int H, 
 int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
                              float *dst, long N, int H, int W, void *stream);
 
+/* ---- network stem: convolution(7, 3, 128, stride=2) + BN + ReLU  models/hourglass_104.py:283, :16-30 ----
+ * images (N,3,H,W) fp32 (H, W multiples of 32) -> out (N,H/2,W/2,128) bf16 NHWC, input conversion and epilogue fused.
+ * w_packed bf16 [128][7 kernel rows][8 taps][4 channels] (tap 7 and channel 3 zero) = the BN-folded weight
+ * (128,3,7,7) permuted to (cout, ky, kx, ch) and zero-padded; bias fp32[128]. */
+int og_stem7x7_bf16(const float *images, const void *w_packed, const float *bias, void *out, int N, int H, int W, int relu,
+                    void *stream);
+
 /* ---- 3x3 stride-1 pad-1 convolution with the epilogue fused, for the small inner hourglass levels ----
  * out = act(conv3x3(x, w) + bias (+ skip)):  convolution.forward models/hourglass_104.py:26-30 / residual.forward
  * :70-79 with BN folded.  x (N,H,W,Cin), w (Cout,3,3,Cin) [= channels_last (Cout,Cin,3,3)], skip/out (N,H,W,Cout),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libog_decoder.so")
-SOURCES = ["abi.cpp", "nms_topk.hip", "upsample.hip", "collect.hip", "group.hip", "flip.hip", "epilogue.hip", "losses.hip", "conv3x3.hip", "encoder.hip"]
+SOURCES = ["abi.cpp", "nms_topk.hip", "upsample.hip", "collect.hip", "group.hip", "flip.hip", "epilogue.hip", "losses.hip", "conv3x3.hip", "encoder.hip", "stem.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: every FMA in the kernels is explicit (bit-exact parity with torch-CPU fp32);
 # correctly-rounded fp32 divide/sqrt is hipcc's default and must stay on (no -ffast-math).

@@ -1,0 +1,144 @@
+// Stem of Hourglass-104: convolution(7, 3, 128, stride=2) + BN + ReLU (models/hourglass_104.py:283, :16-30) on the
+// fp32 NCHW images the reference interface hands over, to bf16 NHWC activations -- the input conversion, the
+// convolution and its epilogue in one kernel.
+//
+// MIOpen runs this layer as an im2col GEMM with K = 147 (3 channels x 49 taps) in 148 us and the bias/ReLU pass over
+// its 210 MB output takes another ~85 us.  Here a workgroup owns a 16x16 output tile x all 128 channels:
+//   * the 37x38-pixel input tile is read from the three fp32 planes once, converted, and kept in LDS as 4-channel
+//     bf16 pixels (8 B, channel 3 = 0);
+//   * K is laid out per kernel row as 8 taps x 4 channels = 32 (tap 7 and channel 3 are zero weights), so one
+//     v_mfma_f32_16x16x32_bf16 covers one kernel row and a B fragment (16 output pixels x 8 k) is one aligned
+//     ds_read_b128: two neighbouring input pixels at column 2*(x + fk), row 2*y + ky;
+//   * the whole 128 x 224 weight matrix (56 KB) sits in LDS; 7 k-steps, no pipeline: two workgroups per CU overlap
+//     each other's load and compute phases;
+//   * epilogue as in the 3x3 kernels: bias + ReLU + one rounding in registers, bf16 tile through LDS, 256-B
+//     contiguous stores.
+#include "og_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kCout = 128, kKRow = 32, kK = 7 * kKRow;          // 224
+constexpr int kWPitch = kK * 2 + 16;                            // 464 B per cout row (29 16-B slots: odd)
+constexpr int kInW = 38, kInH = 37;                             // input tile incl. halo (+1 pad column)
+constexpr int kWBytes = kCout * kWPitch, kInBytes = kInH * kInW * 8;
+constexpr int kOPitch = kCout * 2 + 16;
+static_assert(256 * kOPitch <= kWBytes + kInBytes, "output staging reuses the operand LDS");
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ void __launch_bounds__(256)
+stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__ wp, const float *__restrict__ bias,
+               unsigned short *__restrict__ out, int H, int W, int relu)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const wS = lds, *const inS = lds + kWBytes;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Ho = H >> 1, Wo = W >> 1, tiles_x = Wo >> 4, tiles_y = Ho >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, n = t / tiles_y;
+
+    // ---- weights: 128 rows x 28 16-B chunks -> padded rows
+    for (int i = tid; i < kCout * 28; i += 256) {
+        const int r = i / 28, c = i - r * 28;
+        *reinterpret_cast<u16x8 *>(wS + r * kWPitch + c * 16) = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
+    }
+    // ---- input tile: fp32 planes -> 4-channel bf16 pixels, zero outside the image (pad 3)
+    const size_t plane = (size_t)H * W;
+    const float *src = img + (size_t)n * 3 * plane;
+    const int iy0 = ty * 32 - 3, ix0 = tx * 32 - 3;
+    for (int i = tid; i < kInH * kInW; i += 256) {
+        const int r = i / kInW, c = i - r * kInW;
+        const int y = iy0 + r, x = ix0 + c;
+        u16x4 px = {0, 0, 0, 0};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const size_t o = (size_t)y * W + x;
+            px[0] = f2bf(src[o]);
+            px[1] = f2bf(src[plane + o]);
+            px[2] = f2bf(src[2 * plane + o]);
+        }
+        *reinterpret_cast<u16x4 *>(inS + i * 8) = px;
+    }
+    __syncthreads();
+
+    // ---- 7 k-steps (kernel rows); wave = 4 output rows x 16 columns x 128 couts
+    const int fc = lane & 15, fk = lane >> 4;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int nn = 0; nn < 8; ++nn)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char *pin = inS + ((2 * (wave * 4)) * kInW + 2 * fc + 2 * fk) * 8;
+    const unsigned char *pw = wS + fc * kWPitch + fk * 16;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        bf16x8 pf[4], wf[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(pin + ((2 * m + ky) * kInW) * 8);
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) wf[nn] = *reinterpret_cast<const bf16x8 *>(pw + nn * 16 * kWPitch + ky * 64);
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[nn][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], pf[m], acc[nn][m], 0, 0, 0);
+    }
+
+    // ---- epilogue: bias + ReLU + rounding in registers, bf16 tile through LDS, coalesced stores
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int px = (wave * 4 + m) * 16 + fc;
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) {
+            const int co = nn * 16 + fk * 4;
+            const f32x4 v = acc[nn][m] + *reinterpret_cast<const f32x4 *>(bias + co);
+            u16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(relu ? fmaxf(v[j], 0.f) : v[j]);
+            *reinterpret_cast<u16x4 *>(lds + px * kOPitch + co * 2) = o;
+        }
+    }
+    __syncthreads();
+    const size_t tile_px = ((size_t)n * Ho + ty * 16) * Wo + tx * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int g = tid + 256 * i, px = g >> 4, cg = g & 15;
+        const size_t off = (tile_px + (size_t)(px >> 4) * Wo + (px & 15)) * kCout + cg * 8;
+        *reinterpret_cast<u16x8 *>(out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
+    }
+}
+
+}  // namespace
+
+OG_API int og_stem7x7_bf16(const float *images, const void *w_packed, const float *bias, void *out, int N, int H, int W,
+                           int relu, void *stream)
+{
+    const char *name = "og_stem7x7_bf16";
+    OG_REQUIRE(images && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OG_EINVAL, "%s: H, W must be multiples of 32", name);
+    OG_REQUIRE((uintptr_t)w_packed % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)bias % 16 == 0, OG_EINVAL,
+               "%s: pointers must be 16-byte aligned", name);
+    const long blocks = (long)N * (H / 32) * (W / 32);
+    OG_REQUIRE(blocks < (1l << 31), OG_EINVAL, "%s: too many tiles", name);
+    constexpr int lds = kWBytes + kInBytes;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)stem7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, images,
+                       (const unsigned short *)w_packed, bias, (unsigned short *)out, H, W, relu);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

@@ -214,6 +214,15 @@ class InferenceEngine:
         # optional keypoint-scale head (models/heads.py:112,136): third element of the offset head's output
         self.scale = (_Conv(off_head.scale_convs[self.stage], None, False, dtype, False)
                       if getattr(off_head, 'include_scale', False) else None)
+        # GPU bf16 path: the stem (7x7 stride 2, 3 -> 128) on og_stem7x7_bf16: weight as [cout][ky][8 taps][4 channels]
+        self.stem_w = None
+        c0 = net.pre[0].conv
+        if (fused and int(os.environ.get('OG_ENGINE_STEM', '1')) and tuple(c0.weight.shape) == (128, 3, 7, 7)
+                and tuple(c0.stride) == (2, 2) and tuple(c0.padding) == (3, 3) and height % 32 == 0 and width % 32 == 0):
+            w7 = self.pre[0].w.float().permute(0, 2, 3, 1)                       # (128, ky, kx, ch), BN folded
+            packed = torch.zeros((128, 7, 8, 4), dtype=torch.float32, device=w7.device)
+            packed[:, :, :7, :3] = w7
+            self.stem_w = packed.to(dtype).contiguous()
         # GPU bf16 path: all heads as ONE 1x1 convolution (output channels padded to a multiple of 8); the maps leave
         # through og_nhwc_bf16_to_nchw_f32 (bias added in fp32, one pass) instead of bias / cast / layout passes each
         self.heads_w = None
@@ -235,15 +244,24 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
-        if self.fused:   # fp32 NCHW -> bf16 NHWC in one pass
+        if self.stem_w is not None:   # fused stem: fp32 NCHW images -> conv 7x7 s2 + BN + ReLU -> bf16 NHWC
             lib = _lib.load()
             images = images.float().contiguous()
             n, c, h, w = images.shape
-            x = torch.empty((n, c, h, w), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
-            _lib.check(lib.og_nchw_f32_to_nhwc_bf16(_lib.ptr(images), _lib.ptr(x), n, c, h, w, _lib.stream_ptr(images.device)), lib)
+            x = torch.empty((n, 128, h // 2, w // 2), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
+            _lib.check(lib.og_stem7x7_bf16(_lib.ptr(images), _lib.ptr(self.stem_w), _lib.ptr(self.pre[0].b32), _lib.ptr(x),
+                                           n, h, w, 1, _lib.stream_ptr(images.device)), lib)
+            inter = self.pre[1](x)
         else:
-            x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        inter = _run(self.pre, x)
+            if self.fused:   # fp32 NCHW -> bf16 NHWC in one pass
+                lib = _lib.load()
+                images = images.float().contiguous()
+                n, c, h, w = images.shape
+                x = torch.empty((n, c, h, w), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
+                _lib.check(lib.og_nchw_f32_to_nhwc_bf16(_lib.ptr(images), _lib.ptr(x), n, c, h, w, _lib.stream_ptr(images.device)), lib)
+            else:
+                x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            inter = _run(self.pre, x)
         feat = None
         for s in range(self.stage + 1):
             feat = self.cnvs[s](self.kps[s](inter))

@@ -104,6 +104,28 @@ def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
         assert err <= 6e-3, f'relative error {err}'
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 64, 96), (1, 128, 64)])
+def test_stem7x7_matches_torch(dev, shape):
+    """og_stem7x7_bf16 (fp32 NCHW in, conv 7x7 s2 p3 + bias + ReLU, bf16 NHWC out) vs an fp32 torch convolution of the
+    bf16-rounded operands."""
+    import torch.nn.functional as F
+    n, h, w = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h + w)
+    x = torch.randn(n, 3, h, w, generator=g).to(dev)
+    wt = (torch.randn(128, 3, 7, 7, generator=g) * (1.0 / 147) ** 0.5).to(dev)
+    bias = (torch.randn(128, generator=g) * 0.1).to(dev)
+    packed = torch.zeros((128, 7, 8, 4), device=dev)
+    packed[:, :, :7, :3] = wt.permute(0, 2, 3, 1)
+    packed = packed.to(torch.bfloat16).contiguous()
+    out = torch.full((n, 128, h // 2, w // 2), float('nan'), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.og_stem7x7_bf16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out), n, h, w, 1, _lib.stream_ptr(dev)), lib)
+    ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), wt.to(torch.bfloat16).float(), bias, 2, 3))
+    err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 6e-3, f'relative error {err}'
+    assert lib.og_stem7x7_bf16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out), n, 48, w, 1, _lib.stream_ptr(dev)) == -1
+
+
 def test_conv3x3_rejects_bad_arguments(dev):
     lib = _lib.load()
     x = torch.zeros(1, 64, 4, 4, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
