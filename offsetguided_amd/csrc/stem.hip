@@ -36,7 +36,7 @@ __device__ __forceinline__ unsigned short f2bf(float f)
     return (unsigned short)(u >> 16);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__ wp, const float *__restrict__ bias,
                unsigned short *__restrict__ out, int H, int W, int relu)
 {
@@ -72,43 +72,57 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
     }
     __syncthreads();
 
-    // ---- 7 k-steps (kernel rows); wave = 4 output rows x 16 columns x 128 couts
+    // ---- 7 k-steps (kernel rows); wave = 4 output rows x 16 columns; the 128 couts in two passes of 64 so that the
+    // accumulators take 64 registers, not 128 (with 128 the kernel needed 297 registers = one wave per SIMD, and no
+    // second workgroup on the CU to hide this one's load and store phases: 166 us).  Pass 0's results wait in registers
+    // as packed bf16 until the operands in LDS are no longer needed.
     const int fc = lane & 15, fk = lane >> 4;
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int nn = 0; nn < 8; ++nn)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned char *pin = inS + ((2 * (wave * 4)) * kInW + 2 * fc + 2 * fk) * 8;
     const unsigned char *pw = wS + fc * kWPitch + fk * 16;
+    u16x4 res[2][4][4];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-        bf16x8 pf[4], wf[8];
+    for (int half = 0; half < 2; ++half) {
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(pin + ((2 * m + ky) * kInW) * 8);
+        for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-        for (int nn = 0; nn < 8; ++nn) wf[nn] = *reinterpret_cast<const bf16x8 *>(pw + nn * 16 * kWPitch + ky * 64);
+            for (int m = 0; m < 4; ++m) acc[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nn = 0; nn < 8; ++nn)
+        for (int ky = 0; ky < 7; ++ky) {
+            bf16x8 pf[4], wf[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[nn][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], pf[m], acc[nn][m], 0, 0, 0);
-    }
-
-    // ---- epilogue: bias + ReLU + rounding in registers, bf16 tile through LDS, coalesced stores
-    __syncthreads();
+            for (int m = 0; m < 4; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(pin + ((2 * m + ky) * kInW) * 8);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int px = (wave * 4 + m) * 16 + fc;
+            for (int nn = 0; nn < 4; ++nn)
+                wf[nn] = *reinterpret_cast<const bf16x8 *>(pw + (half * 4 + nn) * 16 * kWPitch + ky * 64);
 #pragma unroll
-        for (int nn = 0; nn < 8; ++nn) {
-            const int co = nn * 16 + fk * 4;
-            const f32x4 v = acc[nn][m] + *reinterpret_cast<const f32x4 *>(bias + co);
-            u16x4 o;
+            for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f2bf(relu ? fmaxf(v[j], 0.f) : v[j]);
-            *reinterpret_cast<u16x4 *>(lds + px * kOPitch + co * 2) = o;
+                for (int m = 0; m < 4; ++m) acc[nn][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], pf[m], acc[nn][m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {  // bias + ReLU + the one rounding
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + (half * 4 + nn) * 16 + fk * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 v = acc[nn][m] + bv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[half][nn][m][j] = f2bf(relu ? fmaxf(v[j], 0.f) : v[j]);
+            }
         }
     }
+
+    // ---- bf16 tile through LDS (the operands are dead now), coalesced stores
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int px = (wave * 4 + m) * 16 + fc;
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                *reinterpret_cast<u16x4 *>(lds + px * kOPitch + ((half * 4 + nn) * 16 + fk * 4) * 2) = res[half][nn][m];
+        }
     __syncthreads();
     const size_t tile_px = ((size_t)n * Ho + ty * 16) * Wo + tx * 16;
 #pragma unroll
