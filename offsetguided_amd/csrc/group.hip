@@ -91,6 +91,8 @@ __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairw
 // it is done UP FRONT for all limb types at once, spread over (limb, k, j) cells -- 4 barriers in
 // total instead of 7 per limb type.  The serial loop then only matches / applies / merges / appends:
 // 5 barriers per limb type (3 when the table is still empty).
+constexpr int kIdPitch = 20;
+
 template <bool GSUB>
 __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
@@ -101,7 +103,10 @@ greedy_group_kernel(GroupArgs A)
     const int K = A.K, L = A.L, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax, LK = L * K;
     // ---- LDS carve-up (pure pointer arithmetic: an integer round trip for alignment would turn
     // everything carved after it into generic pointers, i.e. flat_load instead of ds_read) ----
-    double *r_score = reinterpret_cast<double *>(lds);        // 8-byte items first: the base is 16-byte aligned
+    // keypoint ids of every physical row as ints, 20 per row (17 used): the merge search compares two rows with
+    // 2 x 5 ds_read_b128 instead of 2 x 17 scattered ds_read_b32 of field 5 of the (row, joint, 6) table
+    int *ids = reinterpret_cast<int *>(lds);                   // 16-byte items first: the base is 16-byte aligned
+    double *r_score = reinterpret_cast<double *>(ids + (size_t)mmax * kIdPitch);
     float *p = reinterpret_cast<float *>(r_score + mmax);
     float *lim_all = p;          p += (size_t)LK * 11;     // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
     float *t_score = p;          p += LK;                  // up-front pass: score of valid candidates (-inf otherwise)
@@ -219,6 +224,7 @@ greedy_group_kernel(GroupArgs A)
                 if (cA >= 0) { lsf = fmaxf(LIM(cA, 8), lsf); lst = fmaxf(LIM(cA, 8), lst); }
                 if (cB >= 0) {
                     SUBP(ph, jf, 5) = LIM(cB, 9); SUBP(ph, jt, 5) = LIM(cB, 10);
+                    ids[ph * kIdPitch + jf] = (int)LIM(cB, 9); ids[ph * kIdPitch + jt] = (int)LIM(cB, 10);
 #pragma unroll
                     for (int f = 0; f < 4; ++f) { SUBP(ph, jf, f) = LIM(cB, f); SUBP(ph, jt, f) = LIM(cB, 4 + f); }
                     lsf = fmaxf(LIM(cB, 8), lsf); lst = fmaxf(LIM(cB, 8), lst);
@@ -238,13 +244,16 @@ greedy_group_kernel(GroupArgs A)
                         const int a = (ta << 4) + (tid >> 4), b = (tb << 4) + (tid & 15);
                         if (a < b && b < m0) {
                             const int pa = order[a], pb = order[b];
+                            typedef int v4i __attribute__((ext_vector_type(4)));
+                            const v4i *ra = reinterpret_cast<const v4i *>(ids + pa * kIdPitch);
+                            const v4i *rb = reinterpret_cast<const v4i *>(ids + pb * kIdPitch);
                             int cnt = 0;
 #pragma unroll
-                            for (int j = 0; j < 17; ++j)  // all 34 LDS reads issue back to back
-                                if (j < nkp) {
-                                    const int ia = (int)SUBP(pa, j, 5), ib = (int)SUBP(pb, j, 5);
-                                    cnt += (ia == ib && ia != -1);
-                                }
+                            for (int q = 0; q < 5; ++q) {  // unused tail entries hold -1 in every row
+                                const v4i va = ra[q], vb = rb[q];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) cnt += (va[e] == vb[e] && va[e] != -1);
+                            }
                             if (cnt == 2) { atomicMax(&r_p[a], b); r_d[b] = 1; s_anyQ = 1; }
                         }
                     }
@@ -256,6 +265,10 @@ greedy_group_kernel(GroupArgs A)
                         if (f < rowf && b >= 0 && !r_d[a]) {
                             const int ia = order[a] * rowf + f;
                             sub[ia] = fmaxf(sub[ia], sub[order[b] * rowf + f]);
+                            if (f < nkp) {  // same maximum on the id table (ids are exact in fp32)
+                                const int ja = order[a] * kIdPitch + f;
+                                ids[ja] = max(ids[ja], ids[order[b] * kIdPitch + f]);
+                            }
                         }
                     }
                     __syncthreads();
@@ -311,6 +324,7 @@ greedy_group_kernel(GroupArgs A)
                 if (j == jf) v = (f < 4) ? LIM(c, f) : (f == 4 ? LIM(c, 8) : LIM(c, 9));
                 else if (j == jt) v = (f < 4) ? LIM(c, 4 + f) : (f == 4 ? LIM(c, 8) : LIM(c, 10));
                 sub[(p_first + r) * rowf + jf6] = v;
+                if (jf6 < kIdPitch) ids[(p_first + r) * kIdPitch + jf6] = jf6 == jf ? (int)LIM(c, 9) : (jf6 == jt ? (int)LIM(c, 10) : -1);
             }
             // re-establish the loop invariant for the next limb type
             for (int m = tid; m < M; m += kThreads) { r_a[m] = -1; r_b[m] = -1; r_p[m] = -1; r_d[m] = 0; }
@@ -372,7 +386,8 @@ constexpr size_t kLdsLimit = 159 * 1024;  // 160 KiB per CU minus the static __s
 size_t staging_bytes(int L, int K, int mmax)
 {
     const size_t lk = (size_t)L * K;
-    return (size_t)mmax * 8 + (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64;
+    return (size_t)mmax * kIdPitch * 4 + (size_t)mmax * 8 +
+           (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64;
 }
 
 }  // namespace
