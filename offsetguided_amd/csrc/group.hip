@@ -362,10 +362,15 @@ greedy_group_kernel(GroupArgs A)
     for (int m = wave; m < M; m += kThreads / 64) {  // one wave per row: coalesced copy
         if (r_d[m]) continue;
         const double s = r_score[m];
-        int rank = 0;
-        for (int j = 0; j < M; ++j) {
-            const double o = r_score[j];
-            rank += (!r_d[j]) && (o > s || (o == s && j < m));
+        int rank = 0;  // rows ahead of m in the stable descending order: one lane per candidate row, ballot + popcount
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int j = j0 + lane;
+            bool ahead = false;
+            if (j < M && !r_d[j]) {
+                const double o = r_score[j];
+                ahead = o > s || (o == s && j < m);
+            }
+            rank += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ahead));
         }
         const float *src = sub + order[m] * rowf;
         for (int f = lane; f < rowf; f += 64) {
