@@ -108,11 +108,13 @@ greedy_group_kernel(GroupArgs A)
     int *ids = reinterpret_cast<int *>(lds);                   // 16-byte items first: the base is 16-byte aligned
     double *r_score = reinterpret_cast<double *>(ids + (size_t)mmax * kIdPitch);
     float *p = reinterpret_cast<float *>(r_score + mmax);
-    float *lim_all = p;          p += (size_t)LK * 11;     // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
-    float *t_score = p;          p += LK;                  // up-front pass: score of valid candidates (-inf otherwise)
-    int *t_i2 = (int *)p;        p += LK;                  //                to-index
-    int *t_rank = (int *)p;      p += LK;                  //                rank among the valid ones (stable, descending)
-    int *t_dup = (int *)p;       p += LK;                  //                a better-ranked row has the same to-index
+    const bool wide_ok = (K & 3) == 0 && (mmax & 1) == 0;  // t_score/t_i2/t_dup rows on 16-byte boundaries
+    const int LK4 = (LK + 3) & ~3;                         // array lengths rounded to 16 bytes: t_score .. t_dup are read wide
+    float *lim_all = p;          p += (size_t)((LK * 11 + 3) & ~3);  // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
+    float *t_score = p;          p += LK4;                 // up-front pass: score of valid candidates (-inf otherwise)
+    int *t_i2 = (int *)p;        p += LK4;                 //                to-index
+    int *t_rank = (int *)p;      p += LK4;                 //                rank among the valid ones (stable, descending)
+    int *t_dup = (int *)p;       p += LK4;                 //                a better-ranked row has the same to-index
     int *t_urank = (int *)p;     p += LK;                  //                rank among the valid, non-duplicate ones
     int *kk_arr = (int *)p;      p += L;                   // unique rows per limb type
     int *c_n1 = (int *)p;        p += K;                   // rows with ms==1 per column
@@ -154,7 +156,22 @@ greedy_group_kernel(GroupArgs A)
         if (s == -INFINITY) continue;
         const int l = lk / K, k = lk - l * K, base = l * K, my_i2 = t_i2[lk];
         int rank = 0, dup = 0;
-        for (int j = 0; j < K; ++j) {
+        int j = 0;
+        if (wide_ok) {  // rows start on 16 bytes: four rivals per pair of ds_read_b128
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            for (; j < K; j += 4) {
+                const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
+                const v4i i4 = *reinterpret_cast<const v4i *>(t_i2 + base + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool better = o4[e] != -INFINITY && (o4[e] > s || (o4[e] == s && j + e < k));
+                    rank += better;
+                    dup |= better && (i4[e] == my_i2);
+                }
+            }
+        }
+        for (; j < K; ++j) {
             const float o = t_score[base + j];
             const bool better = o != -INFINITY && (o > s || (o == s && j < k));
             rank += better;
@@ -170,7 +187,19 @@ greedy_group_kernel(GroupArgs A)
         if (s == -INFINITY || t_dup[lk]) continue;
         const int l = lk / K, k = lk - l * K, base = l * K;
         int urank = 0;
-        for (int j = 0; j < K; ++j) {
+        int j = 0;
+        if (wide_ok) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            for (; j < K; j += 4) {
+                const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
+                const v4i d4 = *reinterpret_cast<const v4i *>(t_dup + base + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    urank += (o4[e] != -INFINITY) && !d4[e] && (o4[e] > s || (o4[e] == s && j + e < k));
+            }
+        }
+        for (; j < K; ++j) {
             const float o = t_score[base + j];
             urank += (o != -INFINITY) && !t_dup[base + j] && (o > s || (o == s && j < k));
         }
@@ -392,7 +421,7 @@ size_t staging_bytes(int L, int K, int mmax)
 {
     const size_t lk = (size_t)L * K;
     return (size_t)mmax * kIdPitch * 4 + (size_t)mmax * 8 +
-           (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64;
+           (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64 + 6 * 16;
 }
 
 }  // namespace
