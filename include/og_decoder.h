@@ -180,7 +180,8 @@ int og_stem7x7_bf16(const float *images, const void *w_packed, const float *bias
  * ZERO-INITIALISED once by the caller (its first 256 bytes are read as the zero padding and never written). */
 int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
                     int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
-size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout);
+size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout);        /* upper bound for any H x W with N*H*W = pixels */
+size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout);  /* exact for this shape */
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 void og_conv3x3_debug_stamps(void *buf);

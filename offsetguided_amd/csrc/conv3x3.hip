@@ -620,8 +620,18 @@ OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
 {
     Plan p;
     if (pixels <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || !make_plan(pixels, Cin, Cout, p)) return 0;
-    // (the halo kernel only needs the zero page, which every layout starts with)
     return ws_layout(p, nullptr, nullptr);
+}
+
+// Exact requirement for one layer shape: the halo-tiled kernel of the large levels needs no scratch beyond the fixed
+// head of the layout (the split-K slabs of og_conv3x3_workspace_bytes would be hundreds of MB there).
+OG_API size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const long M = (long)N * H * W;
+    if (Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 && halo_kind(M, H, W, Cin, Cout))
+        return kZeroPageBytes + kMaxTiles * sizeof(int);
+    return og_conv3x3_workspace_bytes(M, Cin, Cout);
 }
 
 OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,

@@ -109,7 +109,7 @@ class _Conv:
             skip = skip.contiguous(memory_format=torch.channels_last)
         lib = _lib.load()
         out = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ws = _conv3x3_workspace(x.device, lib.og_conv3x3_workspace_bytes(n * h * w, c, cout))
+        ws = _conv3x3_workspace(x.device, lib.og_conv3x3_workspace_bytes_nhw(n, h, w, c, cout))
         _lib.check(lib.og_conv3x3_bf16(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
                                        _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout,
                                        int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
