@@ -209,6 +209,10 @@ int og_offset_l1_loss_f32(const float *pred, const float *gt, const float *gt_ps
  * Offsets/scales bit-exact vs the reference; heatmaps to ~2e-7 (device exp). */
 int og_encode_heatmaps_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, int in_w, int in_h,
                            int stride, int sigma, float clip_thre, float *hm, float *bg, void *stream);
+/* og_encode_jitter_f32: HeatMapGenerator.create_jitter_offset encoder/heatmap.py:199-255 -> jit (N,2,h,w): vector from
+ * the cell centre to the nearest annotated keypoint inside a fill_size window, inf elsewhere (bit-exact). */
+int og_encode_jitter_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, int in_w, int in_h,
+                         int stride, int fill_size, float *jit, void *stream);
 int og_encode_offsets_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, const int32_t *jf,
                           const int32_t *jt, int L, int in_w, int in_h, int stride, int fill_size, float min_jscale,
                           const float *sigmas, float *off, float *scale, float *pscale, void *stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "og_conv3x3_workspace_bytes_nhw": (_sz, [_i, _i, _i, _i, _i]),
     "og_conv3x3_debug_stamps": (None, [_vp]),
     "og_encode_heatmaps_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "og_encode_jitter_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "og_encode_offsets_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "og_focal_l2_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _l, _f, _f, _vp, _vp, _vp]),
     "og_offset_l1_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp, _vp, _vp]),

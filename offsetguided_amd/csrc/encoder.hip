@@ -123,6 +123,33 @@ encode_offsets_kernel(const float *__restrict__ joints, const int32_t *__restric
     pscale[o + hw] = ps;
 }
 
+// Jitter offsets (heatmap.py:199-255): two shared channels, vector from the cell centre to the nearest annotated
+// keypoint of ANY channel whose fill window covers the cell (channel-major, then person order; strict <).
+// grid (pixel blocks, N); thread = pixel.
+__global__ void __launch_bounds__(256)
+encode_jitter_kernel(const float *__restrict__ joints, const int32_t *__restrict__ n_persons, int P, int n_kp, int w,
+                     int h, int stride, float fill, float *__restrict__ jit)
+{
+    const int n = blockIdx.y, np_ = n_persons ? min(n_persons[n], P) : P;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= w * h) return;
+    const int x = pix % w, y = pix / w;
+    const float gx = grid(x, stride), gy = grid(y, stride);
+    float bx = INFINITY, by = INFINITY, blen = INFINITY;
+    for (int c = 0; c < n_kp; ++c)
+        for (int p = 0; p < np_; ++p) {
+            const float *j = joints + (((size_t)n * P + p) * n_kp + c) * 4;
+            if (!(j[2] > 0.f)) continue;
+            const Window wd = patch(j[0], j[1], stride, fill);
+            if (x < wd.x0 || x >= wd.x1 || y < wd.y0 || y >= wd.y1) continue;
+            const float ox = j[0] - gx, oy = j[1] - gy;
+            const float len = sqrtf(ox * ox + oy * oy);
+            if (len < blen) { blen = len; bx = ox; by = oy; }
+        }
+    jit[(size_t)n * 2 * h * w + pix] = bx;
+    jit[((size_t)n * 2 + 1) * h * w + pix] = by;
+}
+
 // Keypoint scale maps: channel c holds the from-joint scale written by the LAST limb (skeleton order) with jf == c
 // whose winner covers the pixel (offset.py:193 overwrites limb after limb).  grid (pixel blocks, n_kp, N).
 __global__ void __launch_bounds__(256)
@@ -169,6 +196,20 @@ OG_API int og_encode_heatmaps_f32(const float *joints, const int32_t *n_persons,
     const float gsize = (float)(2 * (int)ceil(sqrt(-ds2 * log((double)clip_thre)) / stride));  // heatmap.py:110-111
     hipLaunchKernelGGL(encode_heatmaps_kernel, dim3((w * h + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, joints,
                        n_persons, P, n_kp, w, h, stride, gsize, (float)ds2, clip_thre, hm, bg);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_encode_jitter_f32(const float *joints, const int32_t *n_persons, int N, int P, int n_kp, int in_w, int in_h,
+                                int stride, int fill_size, float *jit, void *stream)
+{
+    const char *name = "og_encode_jitter_f32";
+    OG_REQUIRE(joints && jit, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && P >= 0 && n_kp > 0 && stride > 0 && fill_size > 0 && in_w >= stride && in_h >= stride && N <= 65535,
+               OG_EINVAL, "%s: bad shape", name);
+    const int w = in_w / stride, h = in_h / stride;
+    hipLaunchKernelGGL(encode_jitter_kernel, dim3((w * h + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, joints, n_persons,
+                       P, n_kp, w, h, stride, (float)fill_size, jit);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -77,9 +77,7 @@ class HeatMaps(_Encoder):
     fill_jitter_size = 3
 
     def encode_batch(self, joints, n_persons=None, mask_miss=None, joint_num=None):
-        """-> (heatmaps (N,17,h,w), background (N,1,h,w) or empty, jitter maps (empty), mask_miss (N,1,h,w) bool)."""
-        if self.include_jitter_offset:
-            raise NotImplementedError('jitter-offset maps (an unused optional head) are not encoded on the device')
+        """-> (heatmaps (N,17,h,w), background (N,1,h,w) or empty, jitter maps (N,2,h,w) or empty, mask_miss (N,1,h,w))."""
         joints, n_persons = _batch_joints(joints, n_persons, self.device)
         n, p, n_kp, _ = joints.shape
         assert self.n_keypoints == (joint_num or n_kp) == n_kp, \
@@ -94,7 +92,14 @@ class HeatMaps(_Encoder):
             self.input_size[0], self.input_size[1], int(self.stride), int(self.sigma), float(self.clip_thre),
             _lib.ptr(hm), _lib.ptr(bg) if bg is not None else None, _lib.stream_ptr(dev)), lib)
         empty = torch.tensor([], device=dev)
-        return hm, (bg if bg is not None else empty), empty, _mask(mask_miss, n, h, w, dev)
+        jit = empty
+        if self.include_jitter_offset:   # heatmap.py:52-55
+            jit = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+            _lib.check(lib.og_encode_jitter_f32(
+                _lib.ptr(joints), _lib.ptr(n_persons) if n_persons is not None else None, n, p, n_kp,
+                self.input_size[0], self.input_size[1], int(self.stride), int(self.fill_jitter_size), _lib.ptr(jit),
+                _lib.stream_ptr(dev)), lib)
+        return hm, (bg if bg is not None else empty), jit, _mask(mask_miss, n, h, w, dev)
 
 
 class OffsetMaps(_Encoder):

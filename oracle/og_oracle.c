@@ -679,6 +679,35 @@ OGO_API void ogo_encode_heatmaps(const float *joints, int P, int n_kp, int in_w,
         }
 }
 
+/* encoder/heatmap.py:199-255 (create_jitter_offset / put_jitter_maps): two shared channels holding, inside a
+ * fill_jitter_size window round every annotated keypoint (all channels, channel-major then person order), the vector from
+ * the cell centre to that keypoint; overlapping windows keep the shorter vector (strict <).  jit (2,h,w) init inf. */
+OGO_API void ogo_encode_jitter(const float *joints, int P, int n_kp, int in_w, int in_h, int stride, int fill_size,
+                               float *jit)
+{
+    const int w = in_w / stride, h = in_h / stride;
+    const size_t hw = (size_t)h * w;
+    for (size_t i = 0; i < 2 * hw; ++i) jit[i] = INFINITY;
+    for (int c = 0; c < n_kp; ++c)
+        for (int p = 0; p < P; ++p) {
+            const float *j = joints + ((size_t)p * n_kp + c) * 4;
+            if (!(j[2] > 0)) continue;
+            int x0, x1, y0, y1;
+            if (!ogo_patch(j[1], stride, (float)fill_size, &y0, &y1)) continue;
+            if (!ogo_patch(j[0], stride, (float)fill_size, &x0, &x1)) continue;
+            if (x1 > w) x1 = w;
+            if (y1 > h) y1 = h;
+            for (int y = y0; y < y1; ++y) {
+                const float oy = j[1] - (float)(y * stride + stride / 2.0 - 0.5);
+                for (int x = x0; x < x1; ++x) {
+                    const float ox = j[0] - (float)(x * stride + stride / 2.0 - 0.5);
+                    float *px = jit + (size_t)y * w + x, *py = px + hw;
+                    if (sqrtf(ox * ox + oy * oy) < sqrtf(*px * *px + *py * *py)) { *px = ox; *py = oy; }
+                }
+            }
+        }
+}
+
 /* encoder/offset.py:98-197 (create_offsetmaps / put_guide_offsets): per limb (fr, to) and person with both joints
  * annotated, a fill_size window round the from-joint holds the vector to the to-joint; where windows overlap the
  * shorter vector wins (strict <: the earlier person keeps ties).  off (2L,h,w) init inf, scale (n_kp,h,w) init nan,

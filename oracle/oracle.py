@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "libog_oracle.so")
 
 __all__ = [
     "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
-    "greedy_group", "group_stats", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "decode",
+    "greedy_group", "group_stats", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "encode_jitter", "decode",
 ]
 
 _lib = None
@@ -57,6 +57,7 @@ def lib():
         L.ogo_flip_cat.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _I32, _I32, _I32, C.c_int, _F, _F]
         L.ogo_encode_heatmaps.argtypes = [_F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _F]
+        L.ogo_encode_jitter.argtypes = [_F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]
         L.ogo_encode_offsets.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, _F, _F, _F, _F]
         L.ogo_greedy_group.argtypes = [_F, C.c_int, C.c_int, _I32, _I32, C.c_int, C.c_double, C.c_float,
@@ -204,6 +205,15 @@ def encode_heatmaps(joints, in_w, in_h, stride=4, sigma=7, clip_thre=0.01):
     hm = np.empty((n_kp, in_h // stride, in_w // stride), np.float32)
     lib().ogo_encode_heatmaps(joints, p, n_kp, in_w, in_h, stride, sigma, clip_thre, hm)
     return hm
+
+
+def encode_jitter(joints, in_w, in_h, stride=4, fill_size=3):
+    """encoder/heatmap.py:199-255: joints (P,17,4) -> (2, h, w) offsets to the nearest keypoint, inf outside."""
+    joints = _f32(joints)
+    p, n_kp = joints.shape[:2]
+    jit = np.empty((2, in_h // stride, in_w // stride), np.float32)
+    lib().ogo_encode_jitter(joints, p, n_kp, in_w, in_h, stride, fill_size, jit)
+    return jit
 
 
 def encode_offsets(joints, skeleton, sigmas, in_w, in_h, stride=4, fill_size=7, min_jscale=1.0):

@@ -34,6 +34,7 @@ def test_oracle_matches_reference_golden(case):
     off, sc, ps = oracle.encode_offsets(j, cd.COCO_PERSON_SKELETON, cd.COCO_PERSON_SIGMAS, size, size)
     assert np.array_equal(off, g[f"{case}_off"]) and np.array_equal(ps, g[f"{case}_pscale"])
     assert np.array_equal(sc, g[f"{case}_scale"], equal_nan=True)
+    assert np.array_equal(oracle.encode_jitter(j, size, size), g[f"{case}_jitter"])
 
 
 def test_encoder_factory_names():
@@ -61,7 +62,7 @@ def test_gpu_encoder_matches_reference_golden(case):
         pytest.fail("GPU tests selected but no HIP device is visible")
     g = load()
     j, size = g[f"{case}_joints"], int(g[f"{case}_size"])
-    encoder.HeatMaps.include_jitter_offset = False
+    encoder.HeatMaps.include_jitter_offset = True
     encoder.HeatMaps.include_background = True
     encoder.OffsetMaps.include_scale = True
     encoder.OffsetMaps.skeleton = cd.COCO_PERSON_SKELETON
@@ -75,7 +76,8 @@ def test_gpu_encoder_matches_reference_golden(case):
     n_persons = np.array([j.shape[0], j.shape[0], 0], np.int32)
     hm, bg, jit, mask = hm_enc.encode_batch(batch, n_persons)
     off, sc, ps, mask2 = off_enc.encode_batch(batch, n_persons)
-    assert jit.numel() == 0 and mask.dtype == torch.bool and bool(mask.all()) and mask.shape == (3, 1, size // 4, size // 4)
+    assert np.array_equal(jit[0].cpu().numpy(), g[f"{case}_jitter"]) and bool(torch.isinf(jit[2]).all())
+    assert mask.dtype == torch.bool and bool(mask.all()) and mask.shape == (3, 1, size // 4, size // 4)
     hm, bg, off, sc, ps = (t.cpu().numpy() for t in (hm, bg, off, sc, ps))
     assert heatmaps_match(hm[0], g[f"{case}_hm"]) and heatmaps_match(hm[1], g[f"{case}_hm"])     # max: order-free
     assert np.array_equal(bg[0, 0], 1 - hm[0].max(0))

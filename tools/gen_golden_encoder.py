@@ -50,6 +50,8 @@ def main():
         ref_hm = hg.create_heatmaps(j, meta)
         og = OffsetMapGenerator([size, size], 4, 7, 1.0, COCO_PERSON_SKELETON)
         ref_off, ref_sc, ref_ps = og.create_offsetmaps(j, meta)
+        ref_jit = hg.create_jitter_offset(j, meta)
+        assert np.array_equal(oracle.encode_jitter(j, size, size), ref_jit), name
         hm = oracle.encode_heatmaps(j, size, size)
         off, sc, ps = oracle.encode_offsets(j, COCO_PERSON_SKELETON, COCO_PERSON_SIGMAS, size, size)
         # offsets / scales: bit-exact.  heatmaps: numpy's SIMD float32 exp vs libm expf differ by <= 2 ulp, and a pixel
@@ -62,7 +64,7 @@ def main():
         print(f'case {name}: P={persons} size={size}: hm max err {worst:.2e}, '
               f'{int((clipped & (d > 0)).sum())} clip-edge pixels, offsets/scales bit-exact; '
               f'{int(np.isfinite(ref_off).sum())} finite offsets')
-        out.update({f'{name}_joints': j, f'{name}_size': np.int64(size), f'{name}_hm': ref_hm,
+        out.update({f'{name}_joints': j, f'{name}_size': np.int64(size), f'{name}_hm': ref_hm, f'{name}_jitter': ref_jit,
                     f'{name}_off': ref_off, f'{name}_scale': ref_sc, f'{name}_pscale': ref_ps})
     np.savez_compressed(os.path.join(GOLD, 'encoder.npz'), **out)
 
