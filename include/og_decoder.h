@@ -114,6 +114,16 @@ int og_collect_limbs_ex_f32(const float *scores, const int64_t *inds, const floa
                             const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
                             float resize_factor, float *limbs, void *stream);
 
+/* ... and with the jitter-offset head (decoder/collect.py:127-138, :154-165, :210-214; include_jitter_offset with
+ * use_jitter_offset): jitter (N,2,..) = the two shared refinement channels; jitter_mode 0: none; 1: maps at input
+ * resolution; 3: stride-4 head output, sampled as F.interpolate(x4, 'bilinear') would (decoder/factory.py:84-88).
+ * The guide point is refined by the vector read at its truncated coordinates ([x][y] indexing of the reference:
+ * square inputs only) and the limb's end points move by the vectors at their own peaks. */
+int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                              int vector_nd, const float *scales, int scales_mode, const float *jitter, int jitter_mode,
+                              int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                              float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
+
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,
  * decoder/factory.py:91-94).

@@ -34,6 +34,7 @@ SIGNATURES = {
     "og_collect_limbs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_collect_limbs_nd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_collect_limbs_ex_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
+    "og_collect_limbs_full_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

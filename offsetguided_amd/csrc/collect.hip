@@ -47,13 +47,21 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
                      const float *__restrict__ offs, int off_lowres, int C, int H, int W,
                      const int32_t *__restrict__ jf, const int32_t *__restrict__ jt, int L, int K,
                      float thre, float min_len, float resize, const float *__restrict__ scales, int scale_mode,
-                     float *__restrict__ limbs)
+                     const float *__restrict__ jitter, int jitter_mode, float *__restrict__ limbs)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Kp = (K + 3) & ~3;                 // to-candidate coordinates interleaved (x,y), padded to 4
     float2 *txy = reinterpret_cast<float2 *>(sm);
     float *ts = sm + 2 * Kp;
     int *ti = reinterpret_cast<int *>(sm + 3 * Kp);
+    // jitter-offset head (collect.py:127-138, :154-165, :210-214): two shared channels; mode 1 = maps at input
+    // resolution, 3 = the stride-4 head output sampled as F.interpolate(x4, 'bilinear') would.  (row, col) are passed as
+    // the reference indexes them -- it reads the guide-point refinement at [x][y].
+    auto jitter_at = [&](int comp, int row, int col) -> float {
+        const int n_ = blockIdx.x / L;
+        if (jitter_mode == 1) return jitter[((size_t)n_ * 2 + comp) * ((long)H * W) + (size_t)row * W + col];
+        return bilinear4_at(jitter + ((size_t)n_ * 2 + comp) * (H / 4) * (W / 4), H / 4, W / 4, row, col);
+    };
     // keypoint-scale head (collect.py:111-122): the scale map of the joint's channel at the candidate's pixel;
     // mode 1 = hi-res map gathered, 2 / 3 = stride-4 map sampled as F.interpolate(x4, bicubic / bilinear) would
     auto scale_at = [&](int ch, long id, int yy, int xx) -> float {
@@ -102,7 +110,15 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
 #pragma unroll
             for (int c = 0; c < ND; ++c) o4[c] = px[(size_t)c * HW + id];
         }
-        const float gx = xf + o4[0] * resize, gy = yf + o4[1] * resize;  // collect.py:152
+        float gx = xf + o4[0] * resize, gy = yf + o4[1] * resize;  // collect.py:152
+        if (jitter_mode) {  // :158-165: refinement read at the truncated guide point, indexed [x][y]
+            const int qx = (int)gx, qy = (int)gy;
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+                const float rx = jitter_at(0, qx, qy), ry = jitter_at(1, qx, qy);
+                gx += rx;
+                gy += ry;
+            }
+        }
         const float gx2 = ND == 4 ? xf + o4[ND - 2] * resize : 0.f, gy2 = ND == 4 ? yf + o4[ND - 1] * resize : 0.f;
         int best = 0;
         float bd = INFINITY;
@@ -130,8 +146,13 @@ collect_limbs_kernel(const float *__restrict__ scores, const int64_t *__restrict
         len = len < min_len ? min_len : len;                        // collect.py:204-205
         const float sc = (s1 * s2) * expf(-bd / len);                // collect.py:208
         float *o = limbs + (((size_t)n * L + l) * K + k) * 13;
-        o[0] = xf; o[1] = yf; o[2] = s1;
-        o[3] = x2; o[4] = y2; o[5] = s2;
+        float x1o = xf, y1o = yf, x2o = x2, y2o = y2;
+        if (jitter_mode) {  // :210-214 (the limb length above used the unmoved end points, :203)
+            x1o += jitter_at(0, yi, xi); y1o += jitter_at(1, yi, xi);
+            x2o += jitter_at(0, id2 / W, id2 % W); y2o += jitter_at(1, id2 / W, id2 % W);
+        }
+        o[0] = x1o; o[1] = y1o; o[2] = s1;
+        o[3] = x2o; o[4] = y2o; o[5] = s2;
         o[6] = (float)(id + (int64_t)cf * HW);                       // collect.py:194-199, :227-228
         o[7] = (float)((int64_t)ti[best] + (int64_t)ct * HW);
         o[8] = bd; o[9] = len; o[10] = sc; o[11] = sc1; o[12] = sc2;
@@ -161,7 +182,21 @@ OG_API int og_collect_limbs_ex_f32(const float *scores, const int64_t *inds, con
                                    const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
                                    float resize_factor, float *limbs, void *stream)
 {
-    const char *name = "og_collect_limbs_ex_f32";
+    return og_collect_limbs_full_f32(scores, inds, offs, off_is_lowres, vector_nd, scales, scales_mode, nullptr, 0, N, C, H, W, jf,
+                                     jt, L, k, thre_hmp, min_len, resize_factor, limbs, stream);
+}
+
+OG_API int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const float *offs, int off_is_lowres,
+                                     int vector_nd, const float *scales, int scales_mode, const float *jitter,
+                                     int jitter_mode, int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L,
+                                     int k, float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream)
+{
+    const char *name = "og_collect_limbs_full_f32";
+    OG_REQUIRE((jitter_mode == 0 || jitter_mode == 1 || jitter_mode == 3) && (jitter_mode == 0) == (jitter == nullptr),
+               OG_EINVAL, "%s: jitter_mode 0 (no head), 1 (hi-res maps) or 3 (stride-4 maps), with a map exactly when not 0", name);
+    OG_REQUIRE(jitter_mode == 0 || (H == W && vector_nd == 2), OG_EUNSUPPORTED,
+               "%s: the jitter refinement indexes its maps [x][y] like the reference: square inputs, 2-component offsets", name);
+    OG_REQUIRE(jitter_mode != 3 || H % 4 == 0, OG_EINVAL, "%s: H,W must be multiples of 4", name);
     OG_REQUIRE(scales_mode >= 0 && scales_mode <= 3 && (scales_mode == 0) == (scales == nullptr), OG_EINVAL,
                "%s: scales_mode 0 (no scale head) .. 3, with a map exactly when it is not 0", name);
     OG_REQUIRE(scales_mode < 2 || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
@@ -173,7 +208,7 @@ OG_API int og_collect_limbs_ex_f32(const float *scores, const int64_t *inds, con
     OG_REQUIRE(k <= 2048, OG_EUNSUPPORTED, "%s: k=%d too large", name, k);
     auto kern = vector_nd == 2 ? collect_limbs_kernel<2> : collect_limbs_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(N * L), dim3(64), (size_t)((k + 3) & ~3) * 16, (hipStream_t)stream, scores, inds, offs,
-                       off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode, limbs);
+                       off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode, jitter, jitter_mode, limbs);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -43,34 +43,39 @@ class LimbsCollect(object):
         return [a for a, _ in skeleton], [b for _, b in skeleton]
 
     def _check_optional_heads(self, jomps_hr, scmps_hr, vector_nd):
-        if self.include_jitter_offset and isinstance(jomps_hr, torch.Tensor):
-            raise NotImplementedError('jitter-offset head is not supported by the HIP decoder')
         if vector_nd not in (2, 4):
             raise NotImplementedError('guiding offsets have 2 components, or 4 with cat_flip_offs')
+
+    def _jitter(self, jomps):
+        """The jitter maps only act when the head exists AND use_jitter_offset (collect.py:154, :212)."""
+        return jomps if self.include_jitter_offset and self.use_jitter_offset and isinstance(jomps, torch.Tensor) else None
 
     def generate_limbs(self, hmps_hr, jomps_hr, offs_hr, scmps_hr, vector_nd=2):
         """(N,C,H,W) heatmaps + (N,2L,H,W) offsets at input resolution -> limbs (N,L,K,13)."""
         assert hmps_hr.shape[-2:] == offs_hr.shape[-2:], 'spatial resolution should be equal'
         self._check_optional_heads(jomps_hr, scmps_hr, vector_nd)
         scales = scmps_hr if self.include_scale and isinstance(scmps_hr, torch.Tensor) else None
-        return self._collect(hmps_hr, offs_hr, off_is_lowres=False, vector_nd=vector_nd, scales=scales, scales_mode=1)
+        return self._collect(hmps_hr, offs_hr, off_is_lowres=False, vector_nd=vector_nd, scales=scales, scales_mode=1,
+                             jitter=self._jitter(jomps_hr), jitter_mode=1)
 
-    def generate_limbs_lowres(self, hmps_hr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic'):
+    def generate_limbs_lowres(self, hmps_hr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic', jomps_lr=None):
         """Same result as generate_limbs(hmps_hr, [], F.interpolate(offs_lr, x4, 'bilinear'), [])
         without building the hi-res offset tensor: K2 samples it at the candidate peaks."""
         assert hmps_hr.shape[-2] == 4 * offs_lr.shape[-2] and hmps_hr.shape[-1] == 4 * offs_lr.shape[-1], \
             'spatial resolution should be equal'
         return self._collect(hmps_hr, offs_lr, off_is_lowres=True, vector_nd=vector_nd, scales=scmps_lr,
-                             scales_mode=2 if scale_inter == 'bicubic' else 3)
+                             scales_mode=2 if scale_inter == 'bicubic' else 3, jitter=self._jitter(jomps_lr), jitter_mode=3)
 
-    def generate_limbs_fused(self, hmps_lr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic'):
+    def generate_limbs_fused(self, hmps_lr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic', jomps_lr=None):
         """Same limbs as generate_limbs(F.interpolate(hmps_lr, x4, 'bicubic'), [], F.interpolate(offs_lr, x4,
         'bilinear'), []) with NEITHER hi-res tensor built: K1-fused upsamples inside the NMS kernel."""
         assert hmps_lr.shape[-2:] == offs_lr.shape[-2:], 'spatial resolution should be equal'
         return self._collect(hmps_lr, offs_lr, off_is_lowres=True, hm_is_lowres=True, vector_nd=vector_nd,
-                             scales=scmps_lr, scales_mode=2 if scale_inter == 'bicubic' else 3)
+                             scales=scmps_lr, scales_mode=2 if scale_inter == 'bicubic' else 3,
+                             jitter=self._jitter(jomps_lr), jitter_mode=3)
 
-    def _collect(self, hmps_hr, offs, off_is_lowres, hm_is_lowres=False, vector_nd=2, scales=None, scales_mode=0):
+    def _collect(self, hmps_hr, offs, off_is_lowres, hm_is_lowres=False, vector_nd=2, scales=None, scales_mode=0,
+                 jitter=None, jitter_mode=0):
         hmps_hr = _lib.require_device(hmps_hr, 'hmps_hr')
         offs = _lib.require_device(offs, 'offs')
         n, c, h, w = hmps_hr.shape
@@ -89,6 +94,12 @@ class LimbsCollect(object):
             scales = _lib.require_device(scales, 'scmps')
             expect = (n, c, h, w) if scales_mode == 1 else (n, c, h // 4, w // 4)
             assert tuple(scales.shape) == expect, f'scale maps {tuple(scales.shape)}, expected {expect}'
+        if jitter is None:
+            jitter_mode = 0
+        else:  # jitter-offset head: two shared channels at input resolution (mode 1) or the stride-4 head output
+            jitter = _lib.require_device(jitter, 'jomps')
+            expect = (n, 2, h, w) if jitter_mode == 1 else (n, 2, h // 4, w // 4)
+            assert tuple(jitter.shape) == expect, f'jitter maps {tuple(jitter.shape)}, expected {expect}'
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
         # one bracket round the whole generate_limbs boundary (K1 + K2): what bench.py prices as "K1"
         with _lib.stage_timer('k1f_fused_limbs' if hm_is_lowres else 'k1_generate_limbs', dev):
@@ -96,9 +107,10 @@ class LimbsCollect(object):
                 scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)
             else:
                 scores, inds = nms_topk_raw(hmps_hr, self.K)
-            _lib.check(lib.og_collect_limbs_ex_f32(
+            _lib.check(lib.og_collect_limbs_full_f32(
                 _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), int(vector_nd),
-                _lib.ptr(scales) if scales is not None else None, int(scales_mode), n, c, h, w,
+                _lib.ptr(scales) if scales is not None else None, int(scales_mode),
+                _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w,
                 _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
                 n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
                 _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)

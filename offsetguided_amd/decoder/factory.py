@@ -129,8 +129,6 @@ class PostProcess(torch.nn.Module):
 
     def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
         """Merge the predictions for [images, mirrored images] (decoder/factory.py:98-146)."""
-        if self.include_jitter_offset and isinstance(jomps, torch.Tensor):
-            raise NotImplementedError('the jitter-offset head is not supported by the HIP decoder')
         hmps = _lib.require_device(hmps, 'hmps')
         offs = _lib.require_device(offs, 'offs')
         n2, c, h, w = hmps.shape
@@ -151,6 +149,11 @@ class PostProcess(torch.nn.Module):
                 _lib.ptr(_lib.int_table(keep, dev)), _lib.ptr(hm_out), _lib.ptr(off_out), _lib.stream_ptr(dev)), lib)
         if cat_flip_offs:
             off_out = off_out.view(n2, -1, h, w)  # the reference's (odd) shape of the same memory, factory.py:127
+        if self.include_jitter_offset and isinstance(jomps, torch.Tensor):  # factory.py:108-113, same ops (exact)
+            jomps = _lib.require_device(jomps, 'jomps')
+            flipped = torch.flip(jomps[n:], [-1])
+            flipped[:, ::2] *= -1
+            jomps = (jomps[:n] + flipped) / 2
         if self.include_scale and isinstance(scmps, torch.Tensor):  # factory.py:141-144, same ops (exact)
             scmps = _lib.require_device(scmps, 'scmps')
             scmps = (scmps[:n] + torch.flip(scmps[n:], [-1])[:, self.keypoints_flips]) / 2
@@ -165,8 +168,6 @@ class PostProcess(torch.nn.Module):
         jomps = out_jomps[self.feat_stage]
         offs = out_offsets[self.feat_stage]
         scmps = out_scales[self.feat_stage]
-        if self.include_jitter_offset and isinstance(jomps, torch.Tensor):
-            raise NotImplementedError('the jitter-offset head is not supported by the HIP decoder')
         vector_nd = 2
         if flip_test:
             hmps, jomps, offs, scmps, vector_nd = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, vector_nd)
@@ -177,10 +178,12 @@ class PostProcess(torch.nn.Module):
             offs = scored_offset(hmps.float(), offs.float(), jf, jt, kernel_size=3)
         # keypoint-scale head: sampled at the peaks from the stride-4 map, as F.interpolate(mode=inter_mode) would give
         scl = scmps.float().contiguous() if self.include_scale and isinstance(scmps, torch.Tensor) else None
+        # jitter-offset head: bilinear x4 (factory.py:84-88), sampled where K2 needs it
+        jit = jomps.float().contiguous() if self.include_jitter_offset and isinstance(jomps, torch.Tensor) else None
         if self.fused_upsample and self.inter_mode == 'bicubic':
-            return self.limb_collect.generate_limbs_fused(hmps, offs, vector_nd, scl, self.inter_mode)
+            return self.limb_collect.generate_limbs_fused(hmps, offs, vector_nd, scl, self.inter_mode, jit)
         hmps_hr = upsample4(hmps, self.inter_mode)
-        return self.limb_collect.generate_limbs_lowres(hmps_hr, offs, vector_nd, scl, self.inter_mode)
+        return self.limb_collect.generate_limbs_lowres(hmps_hr, offs, vector_nd, scl, self.inter_mode, jit)
 
 
 def decoder_cli(parser):

@@ -214,6 +214,9 @@ class InferenceEngine:
         # optional keypoint-scale head (models/heads.py:112,136): third element of the offset head's output
         self.scale = (_Conv(off_head.scale_convs[self.stage], None, False, dtype, False)
                       if getattr(off_head, 'include_scale', False) else None)
+        # optional jitter-offset head (models/heads.py): third element of the heatmap head's output
+        self.jitter = (_Conv(hm_head.jitter_convs[self.stage], None, False, dtype, False)
+                       if getattr(hm_head, 'include_jitter_offset', False) else None)
         # GPU bf16 path: the stem (7x7 stride 2, 3 -> 128) on og_stem7x7_bf16: weight as [cout][ky][8 taps][4 channels]
         self.stem_w = None
         c0 = net.pre[0].conv
@@ -227,7 +230,7 @@ class InferenceEngine:
         # through og_nhwc_bf16_to_nchw_f32 (bias added in fp32, one pass) instead of bias / cast / layout passes each
         self.heads_w = None
         if fused:
-            parts = [h for h in (self.hm, self.off, self.scale) if h is not None]
+            parts = [h for h in (self.hm, self.off, self.scale, self.jitter) if h is not None]
             self.head_channels = [h.w.shape[0] for h in parts]
             w = torch.cat([h.w for h in parts], 0)
             b = torch.cat([h.b32 for h in parts], 0)
@@ -281,9 +284,9 @@ class InferenceEngine:
             return tuple(outs)
         hm = self.hm(feat).float().contiguous(memory_format=torch.contiguous_format)
         off = self.off(feat).float().contiguous(memory_format=torch.contiguous_format)
-        if self.scale is not None:
-            return hm, off, self.scale(feat).float().contiguous(memory_format=torch.contiguous_format)
-        return hm, off
+        extra = tuple(h(feat).float().contiguous(memory_format=torch.contiguous_format)
+                      for h in (self.scale, self.jitter) if h is not None)
+        return (hm, off) + extra
 
     def _capture(self):
         # MIOpen "find" picks per-shape kernels during the warm-up passes (1.4x over the defaults here)
@@ -303,7 +306,8 @@ class InferenceEngine:
 
     @torch.no_grad()
     def forward_raw(self, images):
-        """(hm (N,17,h,w), off (N,38,h,w)[, scale (N,17,h,w)]) fp32 NCHW; graph outputs are reused by the next call."""
+        """(hm (N,17,h,w), off (N,38,h,w)[, scale (N,17,h,w)][, jitter (N,2,h,w)]) fp32 NCHW; graph outputs are reused by
+        the next call."""
         assert tuple(images.shape) == self.shape, f'engine built for {self.shape}, got {tuple(images.shape)}'
         if self._graph is None:
             return self._forward(images.to(self.device))
@@ -312,12 +316,15 @@ class InferenceEngine:
         return self._out
 
     def __call__(self, images):
-        hm, off, *scl = self.forward_raw(images)
+        hm, off, *rest = self.forward_raw(images)
         hms, offs = [None] * self.n_stacks, [None] * self.n_stacks
         hms[self.stage], offs[self.stage] = hm, off
         empty = [[] for _ in range(self.n_stacks)]
-        scales = list(empty)
-        if scl:
+        scales, jitters = list(empty), list(empty)
+        if self.scale is not None:
             scales = [None] * self.n_stacks
-            scales[self.stage] = scl[0]
-        return [(hms, list(empty), list(empty)), (offs, list(empty), scales)]
+            scales[self.stage] = rest.pop(0)
+        if self.jitter is not None:
+            jitters = [None] * self.n_stacks
+            jitters[self.stage] = rest.pop(0)
+        return [(hms, list(empty), jitters), (offs, list(empty), scales)]

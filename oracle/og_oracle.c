@@ -256,9 +256,28 @@ OGO_API void ogo_collect_limbs_nd(const float *scores, const int64_t *inds, cons
     ogo_collect_limbs_ex(scores, inds, offs, off_lowres, NULL, N, C, H, W, jf, jt, L, K, thre, min_len, resize, vector_nd, limbs);
 }
 
+/* jitter_hr (N,2,H,W) or NULL: the jitter-offset head at input resolution (F.interpolate bilinear, factory.py:84-88).
+ * With it (include_jitter_offset) and use_jitter: the guide point is refined by the jitter vector read at its truncated
+ * coordinates -- indexed [x][y] as the reference does (collect.py:158-165: jomps_hr[i, :, xy[0], xy[1]] with xy = (x, y),
+ * in range when 0 <= x < w and 0 <= y < h) -- and after matching the end points move by their own jitter vectors
+ * (:210-214); the limb length (:203) uses the unmoved coordinates. */
+OGO_API void ogo_collect_limbs_jit(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                   const float *scales_hr, const float *jitter_hr, int use_jitter, int N, int C, int H,
+                                   int W, const int *jf, const int *jt, int L, int K, float thre, float min_len,
+                                   float resize, int vector_nd, float *limbs);
+
 OGO_API void ogo_collect_limbs_ex(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
                                   const float *scales_hr, int N, int C, int H, int W, const int *jf, const int *jt, int L,
                                   int K, float thre, float min_len, float resize, int vector_nd, float *limbs)
+{
+    ogo_collect_limbs_jit(scores, inds, offs, off_lowres, scales_hr, NULL, 0, N, C, H, W, jf, jt, L, K, thre, min_len, resize,
+                          vector_nd, limbs);
+}
+
+OGO_API void ogo_collect_limbs_jit(const float *scores, const int64_t *inds, const float *offs, int off_lowres,
+                                   const float *scales_hr, const float *jitter_hr, int use_jitter, int N, int C, int H,
+                                   int W, const int *jf, const int *jt, int L, int K, float thre, float min_len,
+                                   float resize, int vector_nd, float *limbs)
 {
     const int nd = vector_nd;
     const long HW = (long)H * W;
@@ -292,6 +311,13 @@ OGO_API void ogo_collect_limbs_ex(const float *scores, const int64_t *inds, cons
                 }
                 float gx = xf + o4[0] * resize, gy = yf + o4[1] * resize; /* :152 */
                 float gx2 = xf + o4[2] * resize, gy2 = yf + o4[3] * resize;
+                if (jitter_hr && use_jitter) { /* :158-165 */
+                    const int qx = (int)gx, qy = (int)gy; /* .int(): truncation */
+                    if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+                        gx += jitter_hr[((size_t)n * 2 + 0) * HW + (size_t)qx * W + qy];
+                        gy += jitter_hr[((size_t)n * 2 + 1) * HW + (size_t)qx * W + qy];
+                    }
+                }
                 int best = 0;
                 float bd = INFINITY;
                 for (int m = 0; m < K; ++m) { /* :171-177, first minimum */
@@ -310,8 +336,15 @@ OGO_API void ogo_collect_limbs_ex(const float *scores, const int64_t *inds, cons
                 if (len < min_len) len = min_len; /* :204-205 */
                 float sc = (sf[k] * st[best]) * expf(-bd / len); /* :208 */
                 float *o = limbs + (((size_t)n * L + l) * K + k) * 13;
-                o[0] = xf; o[1] = yf; o[2] = sf[k];
-                o[3] = tx[best]; o[4] = ty[best]; o[5] = st[best];
+                float x1 = xf, y1 = yf, x2 = tx[best], y2 = ty[best];
+                if (jitter_hr && use_jitter) { /* :210-214 */
+                    x1 += jitter_hr[((size_t)n * 2 + 0) * HW + idf[k]];
+                    y1 += jitter_hr[((size_t)n * 2 + 1) * HW + idf[k]];
+                    x2 += jitter_hr[((size_t)n * 2 + 0) * HW + idt[best]];
+                    y2 += jitter_hr[((size_t)n * 2 + 1) * HW + idt[best]];
+                }
+                o[0] = x1; o[1] = y1; o[2] = sf[k];
+                o[3] = x2; o[4] = y2; o[5] = st[best];
                 o[6] = (float)(idf[k] + (int64_t)jf[l] * HW);
                 o[7] = (float)(idt[best] + (int64_t)jt[l] * HW);
                 o[8] = bd; o[9] = len; o[10] = sc;

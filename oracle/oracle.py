@@ -52,6 +52,8 @@ def lib():
                                         _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F]
         L.ogo_collect_limbs_nd.argtypes = [_F, _I64, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
+        L.ogo_collect_limbs_jit.argtypes = [_F, _I64, _F, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
         L.ogo_collect_limbs_ex.argtypes = [_F, _I64, _F, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _I32, _I32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _F]
         L.ogo_flip_cat.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -124,7 +126,7 @@ def nms_topk(hm, k):
 
 
 def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_len, resize=1.0, vector_nd=2,
-                  scales_hr=None):
+                  scales_hr=None, jitter_hr=None, use_jitter=True):
     """decoder/collect.py:62-236; `offs` low-res (bilinear-sampled) or hi-res (gathered); vector_nd=4 for the
     cat_flip_offs form (offs then has 4 components per limb)."""
     scores = _f32(scores)
@@ -139,9 +141,13 @@ def collect_limbs(scores, inds, offs, off_lowres, hw_shape, skeleton, thre, min_
     if scales_hr is not None:
         scales_hr = _f32(scales_hr)
         assert scales_hr.shape == (n, c, H, W)
-    lib().ogo_collect_limbs_ex(scores, inds, offs, int(bool(off_lowres)),
-                               scales_hr.ctypes.data if scales_hr is not None else None, n, c, H, W, jf, jt, L, k,
-                               thre, min_len, resize, int(vector_nd), limbs)
+    if jitter_hr is not None:
+        jitter_hr = _f32(jitter_hr)
+        assert jitter_hr.shape == (n, 2, H, W) and H == W, 'the reference indexes the jitter maps [x][y]: square inputs only'
+    lib().ogo_collect_limbs_jit(scores, inds, offs, int(bool(off_lowres)),
+                                scales_hr.ctypes.data if scales_hr is not None else None,
+                                jitter_hr.ctypes.data if jitter_hr is not None else None, int(bool(use_jitter)),
+                                n, c, H, W, jf, jt, L, k, thre, min_len, resize, int(vector_nd), limbs)
     return limbs
 
 
@@ -233,7 +239,7 @@ def encode_offsets(joints, skeleton, sigmas, in_w, in_h, stride=4, fill_size=7, 
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,
            dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False, cat_flip_offs=False,
-           scales_lr=None):
+           scales_lr=None, jitter_lr=None, use_jitter=True):
     """PostProcess.generate_poses (decoder/factory.py:52-96) on low-res head outputs.
 
     flip = (kp_perm, limb_perm, reserve) enables the flip-test merge first.
@@ -252,13 +258,23 @@ def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, pe
             half = scales_lr.shape[0] // 2
             scales_lr = (scales_lr[:half] + scales_lr[half:, list(flip[0])][..., ::-1]) / np.float32(2)
         sc_hr = bicubic4(np.ascontiguousarray(scales_lr))
+    jit_hr = None
+    if jitter_lr is not None:  # jitter head: flip-averaged with x negated (factory.py:108-113), then x4 bilinear
+        jitter_lr = _f32(jitter_lr)
+        if flip is not None:
+            half = jitter_lr.shape[0] // 2
+            fl_j = jitter_lr[half:][..., ::-1].copy()
+            fl_j[:, 0::2] *= np.float32(-1)
+            jitter_lr = (jitter_lr[:half] + fl_j) / np.float32(2)
+        jit_hr = bilinear4(np.ascontiguousarray(jitter_lr))
     hm_hr = bicubic4(hm_lr)
     n, c, H, W = hm_hr.shape
     sc, idx, _, _ = nms_topk(hm_hr, topk_k)
     if materialize_offsets:
         limbs = collect_limbs(sc, idx, bilinear4(off_lr), False, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd,
-                              scales_hr=sc_hr)
+                              scales_hr=sc_hr, jitter_hr=jit_hr, use_jitter=use_jitter)
     else:
-        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd, scales_hr=sc_hr)
+        limbs = collect_limbs(sc, idx, off_lr, True, (H, W), skeleton, thre_hmp, min_len, vector_nd=nd, scales_hr=sc_hr,
+                              jitter_hr=jit_hr, use_jitter=use_jitter)
     poses = [greedy_group(limbs[i], skeleton, c, person_thre, dist_max, use_scale, sort_dim) for i in range(n)]
     return poses, {"hm_hr": hm_hr, "scores": sc, "inds": idx, "limbs": limbs}

@@ -39,6 +39,15 @@ def scale_case_inputs(g):
     return hm, off, scl
 
 
+def jitter_case_inputs(g):
+    """Inputs of a jitter-head fixture (tools/gen_golden.py:jitter_case), sha-guarded."""
+    batch, size, flip, seed = int(g["batch"]), int(g["size"]), bool(g["flip"]), int(g["seed"])
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=7)
+    jit = ((synth.noise_batch(seed + 9, (hm.shape[0], 2, size // 4, size // 4)) - 0.5) * 3.0).astype(np.float32)
+    assert [sha(hm), sha(off), sha(jit)] == list(g["in_sha"]), "synthetic input generator drifted (not a parity failure)"
+    return hm, off, jit
+
+
 def load_case(name):
     """Golden case + regenerated inputs (sha-guarded against generator drift)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -192,11 +192,12 @@ def test_engine_other_shapes_match_eager(dev, batch, height, width):
 
 
 def test_engine_scale_head(dev):
-    """A model built with the keypoint-scale head: the engine returns it as features[omp][2][stage]."""
+    """A model built with the keypoint-scale and jitter-offset heads: the engine returns them as
+    features[omp][2][stage] and features[hmp][2][stage]."""
     import bench
     p = argparse.ArgumentParser()
     models.net_cli(p)
-    model, _ = models.model_factory(p.parse_args(['--no-pretrain', '--include-scale']))
+    model, _ = models.model_factory(p.parse_args(['--no-pretrain', '--include-scale', '--include-jitter-offset']))
     bench.bench_init(model, 5)
     x = torch.randn(1, 3, 128, 128, device=dev)
     model = model.to(dev).eval()
@@ -206,6 +207,8 @@ def test_engine_scale_head(dev):
     r, o = ref[1][2][-1].float(), out[1][2][-1]
     assert o.shape == r.shape == (1, 17, 32, 32) and out[1][2][0] is None
     assert (o - r).abs().max().item() <= 0.05 * r.abs().max().item()
+    rj, oj = ref[0][2][-1].float(), out[0][2][-1]
+    assert oj.shape == rj.shape == (1, 2, 32, 32) and (oj - rj).abs().max().item() <= 0.05 * rj.abs().max().item()
 
 
 def test_engine_matches_reference_golden(dev):

@@ -10,7 +10,7 @@ import torch
 import oracle
 from offsetguided_amd import _lib, decoder, synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, scale_case_inputs,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
                      split_poses)
 
 pytestmark = pytest.mark.gpu
@@ -311,6 +311,34 @@ def test_generate_poses_golden(dev, name):
     poses = proc.generate_poses(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g))
     assert all(p.dtype == np.float32 for p in poses)
     assert_poses_match(split_poses(g), poses, SCORE_TOL)
+
+
+@pytest.mark.parametrize("name", ["jitter256", "jitter256_flip"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_jitter_head_golden(dev, name, fused):
+    """include_jitter_offset / use_jitter_offset: K2 refines the guide point (at the reference's [x][y] index) and moves
+    the limb end points by the jitter vectors sampled from the stride-4 head output."""
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, jit = jitter_case_inputs(g)
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    a = p.parse_args(['--topk', str(FLAGS['topk']), '--thre-hmp', str(FLAGS['thre_hmp']), '--person-thre',
+                      str(FLAGS['person_thre']), '--dist-max', str(FLAGS['dist_max']), '--min-len', str(FLAGS['min_len']),
+                      '--use-jitter-offset', 'True'])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], int(g["batch"])
+    a.include_scale, a.include_jitter_offset = False, True
+    proc = decoder.decoder_factory(a)
+    proc.fused_upsample = fused
+    t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    feats = [([None, t(hm)], [[], []], [None, t(jit)]), ([None, t(off)], [[], []], [[], []])]
+    poses = proc.generate_poses(feats, flip_test=bool(g["flip"]))
+    assert_poses_match(split_poses(g), poses, SCORE_TOL)
+    # without use_jitter_offset the head is ignored (collect.py:154, :212): same poses as without the head
+    proc.limb_collect.use_jitter_offset = False
+    plain = processor(int(g["batch"]))
+    a_ = proc.generate_poses(feats, flip_test=bool(g["flip"]))
+    b_ = plain.generate_poses(features(hm, off, dev), flip_test=bool(g["flip"]))
+    assert all(np.array_equal(x, y) for x, y in zip(a_, b_))
 
 
 def test_scored_offset_golden(dev):

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from offsetguided_amd import synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, scale_case_inputs,
+from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
                      sha, split_poses)
 
 
@@ -102,4 +102,17 @@ def test_scored_offset_matches_reference_golden():
     assert sha(scored) == str(g["scored_sha"])
     poses, _ = oracle.decode(hm, scored, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
                              min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"])
+    assert_poses_match(split_poses(g), poses)
+
+
+@pytest.mark.parametrize("name", ["jitter256", "jitter256_flip"])
+def test_jitter_head_case(name):
+    """Jitter-offset head (include_jitter_offset / use_jitter_offset): refined guide points and end points, incl. the
+    reference's [x][y] indexing of the refinement read; poses (fractional coordinates) exact vs the reference's."""
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, jit = jitter_case_inputs(g)
+    flip = flip_tables() if int(g["flip"]) else None
+    poses, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                             min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
+                             flip=flip, jitter_lr=jit)
     assert_poses_match(split_poses(g), poses)

@@ -192,6 +192,39 @@ def scale_case(decoder, name, seed, batch, size, flip):
     print(f'{name}: poses/img {[len(q) for q in poses]} with the scale head, pose ls err {dp:.2e}')
 
 
+def jitter_case(decoder, name, seed, flip):
+    """Jitter-offset head (include_jitter_offset / use_jitter_offset): jitter maps ride in features[hmp][2]; the guide
+    points and the end points of the limbs are refined by them (collect.py:127-138, :154-165, :210-214)."""
+    batch, size = 2, 256
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=7)
+    nb = hm.shape[0]
+    jit = ((synth.noise_batch(seed + 9, (nb, 2, size // 4, size // 4)) - 0.5) * 3.0).astype(np.float32)   # +-1.5 px
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    a = p.parse_args(['--topk', str(FLAGS['topk']), '--thre-hmp', str(FLAGS['thre_hmp']), '--person-thre',
+                      str(FLAGS['person_thre']), '--dist-max', str(FLAGS['dist_max']), '--min-len', str(FLAGS['min_len']),
+                      '--use-jitter-offset', 'True'])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], batch
+    a.include_scale, a.include_jitter_offset = False, True
+    proc = decoder.decoder_factory(a)
+    t = torch.from_numpy
+    feats = [([t(hm) * 0, t(hm)], [[], []], [t(jit) * 0, t(jit)]), ([t(off) * 0, t(off)], [[], []], [[], []])]
+    poses = proc.generate_poses(feats, flip_test=flip)
+    proc.worker_pool.close()
+    fl = None
+    if flip:
+        perm, rev = offset_hflip(COCO_KEYPOINTS, COCO_PERSON_SKELETON)
+        fl = (heatmap_hflip(COCO_KEYPOINTS), perm, rev)
+    o_poses, _ = oracle.decode(hm, off, COCO_PERSON_SKELETON, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
+                               min_len=FLAGS['min_len'], person_thre=FLAGS['person_thre'], dist_max=FLAGS['dist_max'],
+                               flip=fl, jitter_lr=jit)
+    dp = check_poses(poses, o_poses, name)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), seed=seed, batch=batch, size=size, flip=int(flip),
+                        in_sha=np.array([sha(hm), sha(off), sha(jit)]), n_poses=np.array([len(q) for q in poses]),
+                        poses=np.concatenate(poses, 0))
+    print(f'{name}: poses/img {[len(q) for q in poses]} with the jitter head, pose ls err {dp:.2e}')
+
+
 def scored_case(decoder):
     """Optional heatmap-weighted offsets (decoder/offset.py:8-43, generate_poses(scored_off=True)): the function itself
     (bit-exact: same torch ops) and the poses it leads to."""
@@ -331,6 +364,8 @@ def main():
     decoder = load_reference()
     pipeline_case(decoder, 'pipe256_flipcat_p6', 306, 2, 256, True, 6, cat=True)
     pipeline_case(decoder, 'pipe640_flipcat', 642, 2, 640, True, None, cat=True)
+    jitter_case(decoder, 'jitter256', 601, False)
+    jitter_case(decoder, 'jitter256_flip', 602, True)
     scored_case(decoder)
     scale_case(decoder, 'scale256', 401, 2, 256, False)
     scale_case(decoder, 'scale256_flip', 402, 2, 256, True)
