@@ -77,6 +77,28 @@ class GreedyGroup(object):
 
 
 def soft_nms(subset, suppressed_v=0):
-    """Present in the reference API (decoder/group.py:249-283) but dead there (its only call is
-    commented out, :183); not part of the hot path."""
-    raise NotImplementedError('soft_nms is unused by the reference decoder and not implemented')
+    """Keypoint-level suppression over finished poses (decoder/group.py:249-283; its only call there, :183, is commented
+    out).  Host-side like the reference: `subset` is the list / array of (n_keypoints, 6) poses already copied back.
+    Per keypoint type an occupancy grid: a keypoint that lands on an occupied cell gets the score `suppressed_v`,
+    otherwise it occupies the square of half-width max(10, scale) round itself.  Modifies `subset` in place."""
+    if not len(subset):
+        return subset
+    occupied = np.zeros((len(subset[0]),
+                         int(max(np.max(ann[:, 1]) for ann in subset) + 1),
+                         int(max(np.max(ann[:, 0]) for ann in subset) + 1)), dtype=np.uint8)
+    for ann in subset:
+        joint_scales = np.maximum(10.0, ann[:, 3])
+        assert len(occupied) == len(ann)
+        for xyv, occ, width in zip(ann[:, :3], occupied, joint_scales):
+            if xyv[2] == -1:
+                continue
+            x = np.clip(xyv[0], 0.0, occ.shape[1] - 1).astype(int)
+            y = np.clip(xyv[1], 0.0, occ.shape[0] - 1).astype(int)
+            if occ[y, x]:
+                xyv[2] = suppressed_v
+            else:  # scalar_square_add_single (:280-285)
+                minx, miny = max(0, int(xyv[0] - width)), max(0, int(xyv[1] - width))
+                maxx = max(minx + 1, min(occ.shape[1], int(xyv[0] + width) + 1))
+                maxy = max(miny + 1, min(occ.shape[0], int(xyv[1] + width) + 1))
+                occ[miny:maxy, minx:maxx] += 1
+    return subset

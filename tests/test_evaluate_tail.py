@@ -40,3 +40,17 @@ def test_cli_surface():
                                '--opt-level', 'O2', '--dataset', 'test-dev'])
     assert a.topk == 32 and a.flip_test and a.all_images and a.headnets == ['hmp', 'omp'] and a.strides == [4, 4]
     assert a.resize_mode == 'bicubic' and a.min_len == 0.5 and a.sort_dim == 2 and a.use_scale is True
+
+
+def test_soft_nms_matches_reference_golden():
+    """decoder/group.py:249-283 (host-side, dead code upstream): golden pose sets from the imported reference."""
+    import numpy as np
+    from offsetguided_amd.decoder import soft_nms
+    from helpers import GOLDEN
+    g = np.load(f"{GOLDEN}/soft_nms.npz")
+    o = 0
+    for n in g["counts"]:
+        poses = [p.copy() for p in g["poses_in"][o:o + n]]
+        got = soft_nms(poses, suppressed_v=0)
+        assert len(got) == n and all(np.array_equal(a, b) for a, b in zip(got, g["poses_out"][o:o + n]))
+        o += n
