@@ -174,6 +174,14 @@ int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, int H, 
 int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
                              float *dst, long N, int H, int W, void *stream);
 
+/* ---- evaluate.py input side (the rescale by cv2.resize is NOT included) ----
+ * CenterPad + ToTensor + Normalize, transforms/pad.py:40-66 + evaluate.py:163-168: img (h,w,3) uint8 RGB on the device ->
+ * out (3,target_h,target_w) fp32 = (px/255 - mean)/std with px the image pixel or `fill3` (124,116,104 in the
+ * reference); mean3/std3/fill3 are HOST arrays of 3 floats; ltrb (host int[4], may be NULL) receives the paddings that
+ * the annotations / annotations_inverse need. */
+int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int target_h, int target_w, const float *mean3,
+                               const float *std3, const float *fill3, float *out, int *ltrb, void *stream);
+
 /* ---- network stem: convolution(7, 3, 128, stride=2) + BN + ReLU  models/hourglass_104.py:283, :16-30 ----
  * images (N,3,H,W) fp32 (H, W multiples of 32) -> out (N,H/2,W/2,128) bf16 NHWC, input conversion and epilogue fused.
  * w_packed bf16 [128][7 kernel rows][8 taps][4 channels] (tap 7 and channel 3 zero) = the BN-folded weight

@@ -169,3 +169,50 @@ OG_API int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
+
+// ---- input side of evaluate.py (the part that can be pinned without cv2) ------------------------------
+// CenterPad(fill 124,116,104) + ToTensor + Normalize (transforms/pad.py:40-66, evaluate.py:163-168) on an already
+// rescaled uint8 HWC image, in one pass: out[c][Y][X] = (px/255 - mean[c]) / std[c] in fp32 (torchvision's
+// div(255), sub_(mean), div_(std)), px = image pixel or the fill colour.  The rescale itself (cv2.resize) is not here.
+namespace {
+
+struct PrepArgs {
+    float mean[3], stdv[3], fill[3];
+};
+
+__global__ void __launch_bounds__(256)
+center_pad_normalize_kernel(const unsigned char *__restrict__ img, int h, int w, int left, int top, int TH, int TW,
+                            PrepArgs a, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)TH * TW) return;
+    const int X = (int)(i % TW), Y = (int)(i / TW);
+    const int x = X - left, y = Y - top;
+    const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+    const unsigned char *p = img + ((size_t)(inside ? y : 0) * w + (inside ? x : 0)) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = inside ? (float)p[c] : a.fill[c];
+        out[(size_t)c * TH * TW + i] = (v / 255.f - a.mean[c]) / a.stdv[c];
+    }
+}
+
+}  // namespace
+
+OG_API int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int target_h, int target_w, const float *mean3,
+                                      const float *std3, const float *fill3, float *out, int *ltrb, void *stream)
+{
+    const char *name = "og_center_pad_normalize_u8";
+    OG_REQUIRE(img && mean3 && std3 && fill3 && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(h > 0 && w > 0 && target_h >= h && target_w >= w, OG_EINVAL, "%s: the image must fit the target", name);
+    // transforms/pad.py:43-55: left = int((T - w) / 2.0), top likewise; the rest goes right / down
+    const int left = (int)((target_w - w) / 2.0), top = (int)((target_h - h) / 2.0);
+    if (ltrb) { ltrb[0] = left; ltrb[1] = top; ltrb[2] = target_w - w - left; ltrb[3] = target_h - h - top; }
+    PrepArgs a;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; a.fill[c] = fill3[c]; }
+    const long total = (long)target_h * target_w;
+    hipLaunchKernelGGL(center_pad_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       h, w, left, top, target_h, target_w, a, out);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
