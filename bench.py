@@ -9,7 +9,7 @@ A step = one batch of 8 images (16 through the backbone with --flip) resident in
 bf16 channels-last backbone replayed as a HIP graph -> head outputs (+ synthetic GT-like
 maps, see below) -> K1a bicubic x4 -> K1 NMS+top-k -> K2 limb collection -> K3 greedy grouping
 -> poses copied to pinned host memory.  Steps are software-pipelined one deep (the host picks
-up batch i-1's poses after queueing batch i), all GPU work is in order on one stream.
+up batch i-1's poses after queueing batch i); the grouping kernel and the pose copy run on a side stream.
 
 Random-init networks emit ~constant maps (no keypoints), which would leave the decoder with
 nothing to do; as SURVEY.md section 8(d) prescribes, synthetic GT-like stride-4 maps (4-20
@@ -26,8 +26,16 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# One MIOpen user database per rank: with N ranks on a node every process runs MIOpen's kernel search while the engine
+# is built, and they would otherwise all write the same sqlite files under ~/.config/miopen.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
+    _db = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'miopen_rank%s' % os.environ.get('LOCAL_RANK', '0'))
+    os.makedirs(_db, exist_ok=True)
+    os.environ['MIOPEN_USER_DB_PATH'] = _db
+    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', _db)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
