@@ -200,6 +200,16 @@ int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void 
                     int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout);        /* upper bound for any H x W with N*H*W = pixels */
 size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout);  /* exact for this shape */
+/* General form for the remaining convolutions of the hourglass: ksize 1 (pad 0) or 3 (pad 1), stride 1 or 2 --
+ * residual.conv1 with stride 2 and the 1x1 projection `skip` (models/hourglass_104.py:54-57, :63-68), the 1x1
+ * inters_/cnvs_ junction (:239-250) and the head convolutions (models/heads.py).  x (N,Hin,Win,Cin),
+ * w (Cout,ksize,ksize,Cin), skip/out (N,Hout,Wout,Cout) with Hout = (Hin + 2*(ksize/2) - ksize)/stride + 1;
+ * same dtype / channel / workspace rules as og_conv3x3_bf16 (which is og_conv2d_bf16 with ksize 3, stride 1);
+ * workspace: og_conv2d_workspace_bytes (0 = unsupported shape). */
+int og_conv2d_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin, int Win,
+                   int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes,
+                   void *stream);
+size_t og_conv2d_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 void og_conv3x3_debug_stamps(void *buf);

@@ -47,7 +47,8 @@ struct ConvArgs {
     float *partial;              // [tile][ksplit][NT*MT][256 lanes] x 4 fp32 slabs (ksplit > 1)
     int *counters;               // [tiles] arrival tickets, zero between launches
     const unsigned short *zero;  // >= 16 B of zeros
-    int N, H, W, Cin, Cout, M;
+    int N, H, W, Cin, Cout, M;   // H, W = OUTPUT height / width; M = N*H*W output pixels
+    int Hin, Win, stride, taps;  // input height / width, stride 1|2, taps 9 (3x3, pad 1) | 1 (1x1, pad 0)
     int n_tiles, steps_per_split, ksplit, relu;
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
@@ -138,37 +139,44 @@ conv3x3_kernel(ConvArgs a)
     const int chunks = a.Cin >> 6;                  // K steps per tap
 
     // ---- loader set-up: piece p = tid + 256*i -> tile row p/8, LDS slot p%8, source chunk slot^((row>>1)&7)
+    // output pixel m -> centre input pixel (y*stride, x*stride); a 3x3 tap adds (dy, dx) in -1..1, a 1x1 conv has the
+    // centre tap only (pad 0)
     const unsigned short *px_ptr[PX];
     uint32_t px_mask[PX];
+    const int taps = a.taps;
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
         const int m = m0 + r;
-        const int xw = m % a.W, t = m / a.W, y = t % a.H;
+        const int xw = m % a.W, t = m / a.W, y = t % a.H, img = t / a.H;
+        const int yc = y * a.stride, xc = xw * a.stride;
         uint32_t mask = 0;
         if (m < a.M) {
+            if (taps == 1) mask = 1u;
+            else {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = xw + tap % 3 - 1;
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) mask |= 1u << tap;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int yy = yc + tap / 3 - 1, xx = xc + tap % 3 - 1;
+                    if (yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win) mask |= 1u << tap;
+                }
             }
         }
         px_mask[i] = mask;
-        px_ptr[i] = a.x + (size_t)(m < a.M ? m : 0) * a.Cin + c * 8;
+        px_ptr[i] = a.x + (m < a.M ? ((size_t)img * a.Hin + yc) * a.Win + xc : (size_t)0) * a.Cin + c * 8;
     }
     const unsigned short *w_ptr[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_ptr[i] = a.w + (size_t)(n0 + r) * 9 * a.Cin + c * 8;
+        w_ptr[i] = a.w + (size_t)(n0 + r) * taps * a.Cin + c * 8;
     }
     const int lds_piece = (wave * 64) * 16;  // wave-uniform; + lane*16 is implied by the DMA
 
     auto issue = [&](int step_local, int buf) {
         const int step = step0 + step_local;
         const int tap = step / chunks, ci0 = (step - tap * chunks) << 6;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const long shift = ((long)dy * a.W + dx) * a.Cin + ci0;
+        const int dy = taps == 1 ? 0 : tap / 3 - 1, dx = taps == 1 ? 0 : tap - (tap / 3) * 3 - 1;
+        const long shift = ((long)dy * a.Win + dx) * a.Cin + ci0;
         unsigned char *base = lds + buf * kStage + lds_piece;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
@@ -555,9 +563,9 @@ struct Plan {
 
 // Tile and K split.  Measured inside the network (bs8, tools/bb_bench.py, whole-forward ms): 64-wide tiles with
 // ~6 K splits 10.82, 64/3 10.89, shape-dependent 128-wide tiles 11.15, 128/3 11.85, no split 11.82; MIOpen 11.59.
-bool make_plan(long M, int Cin, int Cout, Plan &p)
+bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9)
 {
-    const int steps = 9 * Cin / 64;
+    const int steps = taps * Cin / 64;
     const char *e = getenv("OG_CONV_PLAN");  // "bm,ksplit,stages" override for tuning
     int bm = 64, force_split = 0, force_stages = 0;
     if (e) sscanf(e, "%d,%d,%d", &bm, &force_split, &force_stages);
@@ -565,12 +573,14 @@ bool make_plan(long M, int Cin, int Cout, Plan &p)
     if (bm == 128 && Cout % 128 != 0) return false;
     p.bm = p.bn = bm;
     p.stages = bm == 128 ? 3 : 4;
-    if (force_stages == 4 || (force_stages == 3 && bm == 128) || (force_stages == 8 && bm == 64)) p.stages = force_stages;
+    if (steps < 3) p.stages = 3;  // 1x1 convolutions with Cin = 128: two K steps
+    if (force_stages == 4 || force_stages == 3 || (force_stages == 8 && bm == 64)) p.stages = force_stages;
     p.m_tiles = (int)((M + bm - 1) / bm);
     p.n_tiles = Cout / bm;
     // per layer inside the network (rocprofv3, conv + finish, us): 20x20 ks 2/3/6/9 = 34.9/31.4/36.2/41.1,
     // 10x10 = 19.5/16.2/15.6/18.5, 5x5 = 22.5/17.4/12.7/12.7
-    const int max_ks = M >= 2048 ? 3 : 6;
+    // enough tiles to fill the chip several times over (the stride-2 / 1x1 layers of the large levels): no K split
+    const int max_ks = (long)p.m_tiles * p.n_tiles >= 1024 ? 1 : M >= 2048 ? 3 : 6;
     int best = 1;
     for (int ks = 2; ks <= max_ks; ++ks)
         if (steps % ks == 0 && steps / ks >= 4 && steps / ks >= p.stages - 1) best = ks;
@@ -623,34 +633,49 @@ OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
     return ws_layout(p, nullptr, nullptr);
 }
 
-// Exact requirement for one layer shape: the halo-tiled kernel of the large levels needs no scratch beyond the fixed
+static inline int conv_out_dim(int in, int ksize, int stride) { return (in + 2 * (ksize / 2) - ksize) / stride + 1; }
+
+// Exact requirement for one layer: the halo-tiled kernel of the large levels needs no scratch beyond the fixed
 // head of the layout (the split-K slabs of og_conv3x3_workspace_bytes would be hundreds of MB there).
-OG_API size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout)
+OG_API size_t og_conv2d_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride)
 {
-    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    if (N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return 0;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    const int H = conv_out_dim(Hin, ksize, stride), W = conv_out_dim(Win, ksize, stride);
     const long M = (long)N * H * W;
-    if (Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 && halo_kind(M, H, W, Cin, Cout))
-        return kZeroPageBytes + kMaxTiles * sizeof(int);
-    return og_conv3x3_workspace_bytes(M, Cin, Cout);
+    if (ksize == 3 && stride == 1 && halo_kind(M, H, W, Cin, Cout)) return kZeroPageBytes + kMaxTiles * sizeof(int);
+    Plan p;
+    if (!make_plan(M, Cin, Cout, p, ksize * ksize)) return 0;
+    return ws_layout(p, nullptr, nullptr);
 }
 
-OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,
-                           int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
+OG_API size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout)
 {
-    const char *name = "og_conv3x3_bf16";
+    return og_conv2d_workspace_bytes(N, H, W, Cin, Cout, 3, 1);
+}
+
+static int conv_run(const char *name, const void *x, const void *w, const float *bias, const void *skip, void *out, int N,
+                    int Hin, int Win, int Cin, int Cout, int ksize, int stride, int relu, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
     OG_REQUIRE(x && w && bias && out && workspace, OG_EINVAL, "%s: null pointer", name);
-    OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(N > 0 && Hin > 0 && Win > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), OG_EUNSUPPORTED,
+               "%s: kernel size %d / stride %d (1x1 and 3x3, stride 1 and 2 only)", name, ksize, stride);
     OG_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0, OG_EUNSUPPORTED,
                "%s: channels must be multiples of 64 (got %d -> %d)", name, Cin, Cout);
-    const long M = (long)N * H * W;
-    OG_REQUIRE(M * (long)(Cin > Cout ? Cin : Cout) < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
+    const int H = conv_out_dim(Hin, ksize, stride), W = conv_out_dim(Win, ksize, stride), taps = ksize * ksize;
+    const long M = (long)N * H * W, Min = (long)N * Hin * Win;
+    OG_REQUIRE(Min * (long)Cin < (1l << 30) && M * (long)Cout < (1l << 30), OG_EUNSUPPORTED,
+               "%s: tensor too large (>= 2 GiB)", name);
     OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
     hipStream_t st = (hipStream_t)stream;
-    if (const int kind = halo_kind(M, H, W, Cin, Cout)) {
+    if (const int kind = (ksize == 3 && stride == 1) ? halo_kind(M, H, W, Cin, Cout) : 0) {
         ConvArgs h = {};
         h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
         h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
+        h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
         h.stamps = g_stamps;
         h.x_bytes = (int)(M * Cin * 2);
         h.w_bytes = Cout * 9 * Cin * 2;
@@ -674,12 +699,12 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
         return OG_OK;
     }
     Plan p;
-    OG_REQUIRE(make_plan(M, Cin, Cout, p), OG_EUNSUPPORTED, "%s: no tile plan", name);
+    OG_REQUIRE(make_plan(M, Cin, Cout, p, taps), OG_EUNSUPPORTED, "%s: no tile plan", name);
     OG_REQUIRE((size_t)p.m_tiles * p.n_tiles <= kMaxTiles, OG_EUNSUPPORTED, "%s: too many tiles", name);
-    const size_t need = og_conv3x3_workspace_bytes(M, Cin, Cout);
+    const size_t need = ws_layout(p, nullptr, nullptr);
     OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu bytes", name, workspace_bytes, need);
 
-    ConvArgs a;
+    ConvArgs a = {};
     a.x = (const unsigned short *)x;
     a.w = (const unsigned short *)w;
     a.bias = bias;
@@ -691,6 +716,7 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     a.counters = (int *)((char *)workspace + c_off);
     a.partial = (float *)((char *)workspace + s_off);
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = (int)M;
+    a.Hin = Hin; a.Win = Win; a.stride = stride; a.taps = taps;
     a.stamps = g_stamps;
     a.in_launch_reduce = p.in_launch;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
@@ -709,6 +735,7 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);
     else if (p.bm == 128) CONV_LAUNCH(128, 3);
     else if (p.stages == 8) CONV_LAUNCH(64, 8);
+    else if (p.stages == 3) CONV_LAUNCH(64, 3);
     else CONV_LAUNCH(64, 4);
 #undef CONV_LAUNCH
     if (p.ksplit > 1 && !p.in_launch) {
@@ -719,4 +746,19 @@ OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, cons
     }
     OG_LAUNCH_CHECK(name);
     return OG_OK;
+}
+
+OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,
+                           int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return conv_run("og_conv3x3_bf16", x, w, bias, skip, out, N, H, W, Cin, Cout, 3, 1, relu, workspace, workspace_bytes,
+                    stream);
+}
+
+OG_API int og_conv2d_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin,
+                          int Win, int Cin, int Cout, int ksize, int stride, int relu, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    return conv_run("og_conv2d_bf16", x, w, bias, skip, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
+                    workspace_bytes, stream);
 }

@@ -87,7 +87,8 @@ class _Conv:
         self.b = b.to(dtype)
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
         self.fused = fused and w.shape[0] % 8 == 0
-        self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1)
+        strides = ((1, 1), (2, 2)) if int(os.environ.get('OG_ENGINE_CONV_S2', '1')) else ((1, 1),)
+        self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) in strides
                        and tuple(conv.padding) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
 
     def raw(self, x):
@@ -95,24 +96,30 @@ class _Conv:
 
     def __call__(self, x, skip=None):
         n, c, h, w = x.shape
-        if self.hip3x3 and (n * h * w <= CONV3X3_MAX_PIXELS or (
-                n * h * w >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
-                and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
-            return self._hip(x, skip)
+        if self.hip3x3:
+            st = self.stride[0]
+            pixels = n * ((h - 1) // st + 1) * ((w - 1) // st + 1)
+            # stride 2: the split-K kernel wins where M is small (40x40 -> 20x20 and below at bs8: 30 / 15 / 12 us against
+            # MIOpen + epilogue 48 / 30 / 26); the large stride-2 layers stay on MIOpen (CK is 1.2-1.6x faster there)
+            if pixels <= CONV3X3_MAX_PIXELS or (st == 1 and (
+                    pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
+                    and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
+                return self._hip(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
 
     def _hip(self, x, skip):
         n, c, h, w = x.shape
-        cout = self.w.shape[0]
+        cout, st = self.w.shape[0], self.stride[0]
         assert x.is_contiguous(memory_format=torch.channels_last)
         if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
             skip = skip.contiguous(memory_format=torch.channels_last)
         lib = _lib.load()
-        out = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ws = _conv3x3_workspace(x.device, lib.og_conv3x3_workspace_bytes_nhw(n, h, w, c, cout))
-        _lib.check(lib.og_conv3x3_bf16(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
-                                       _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout,
-                                       int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
+        out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        ws = _conv3x3_workspace(x.device, lib.og_conv2d_workspace_bytes(n, h, w, c, cout, 3, st))
+        _lib.check(lib.og_conv2d_bf16(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
+                                      _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout, 3, st,
+                                      int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
         return out
 
 

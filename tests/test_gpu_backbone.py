@@ -77,6 +77,55 @@ def test_conv3x3_matches_torch(dev, shape, reduce_mode, monkeypatch):
     assert ws[:256].count_nonzero().item() == 0              # the zero page is never written
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 20, 384, 384, 3, 2), (2, 20, 20, 384, 384, 1, 2), (8, 5, 5, 512, 384, 1, 1),
+                                   (8, 10, 10, 384, 512, 3, 2), (8, 10, 10, 384, 512, 1, 2), (3, 7, 9, 64, 128, 3, 2),
+                                   (3, 7, 9, 128, 64, 1, 2), (1, 1, 1, 128, 64, 1, 1), (2, 64, 64, 128, 256, 3, 2),
+                                   (2, 64, 64, 128, 256, 1, 2), (2, 80, 80, 256, 256, 1, 1), (2, 33, 31, 128, 256, 3, 1),
+                                   (1, 96, 96, 256, 384, 3, 2), (4, 160, 160, 256, 64, 1, 1)])
+def test_conv2d_matches_torch(dev, shape):
+    """og_conv2d_bf16 (1x1 / 3x3, stride 1 / 2, fused epilogue) vs an fp32 torch convolution of the same bf16 operands."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout, k, st = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + cin + k * 7 + st)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (k * k * cin)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    base = F.conv2d(x.float(), wt.float(), bias, st, k // 2)
+    ho, wo = base.shape[2:]
+    skip = torch.randn(n, cout, ho, wo, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    need = lib.og_conv2d_workspace_bytes(n, h, w, cin, cout, k, st)
+    assert need > 0
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    for use_skip, relu in ((True, 1), (False, 0)):
+        ref = base + skip.float() if use_skip else base
+        if relu:
+            ref = F.relu(ref)
+        out = torch.full_like(skip, float('nan'))
+        for _ in range(2):
+            _lib.check(lib.og_conv2d_bf16(_lib.ptr(x), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None,
+                                          _lib.ptr(out), n, h, w, cin, cout, k, st, relu, _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_ptr(dev)), lib)
+        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 6e-3, f'relative error {err}'
+    assert ws[:256].count_nonzero().item() == 0
+
+
+def test_conv2d_rejects_bad_arguments(dev):
+    lib = _lib.load()
+    x = _nhwc(1, 64, 8, 8, dev=dev)
+    wt = _nhwc(64, 64, 3, 3, dev=dev)
+    b = torch.zeros(64, device=dev)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(x)
+    for k, st in ((5, 1), (3, 3), (2, 1)):
+        rc = lib.og_conv2d_bf16(_lib.ptr(x), _lib.ptr(wt), _lib.ptr(b), None, _lib.ptr(out), 1, 8, 8, 64, 64, k, st, 0,
+                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        assert rc == _lib.OG_EUNSUPPORTED
+        assert lib.og_conv2d_workspace_bytes(1, 8, 8, 64, 64, k, st) == 0
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256),
                                    (1, 4, 40, 64, 128), (2, 40, 40, 384, 384), (1, 12, 40, 128, 256)])
 def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):

@@ -16,6 +16,14 @@ SHAPES = [(8, 5, 5, 512, 512), (8, 10, 10, 384, 384), (8, 20, 20, 384, 384), (8,
           (8, 160, 160, 256, 256), (16, 160, 160, 256, 256), (16, 80, 80, 256, 256)]
 
 
+# the hourglass's other convolutions at bs8 640x640: (N, Hin, Win, Cin, Cout, ksize, stride)
+SHAPES2 = [(8, 320, 320, 128, 256, 3, 2), (8, 320, 320, 128, 256, 1, 2), (8, 160, 160, 256, 256, 1, 1),
+           (8, 160, 160, 256, 256, 3, 2), (8, 160, 160, 256, 256, 1, 2), (8, 80, 80, 256, 384, 3, 2),
+           (8, 80, 80, 256, 384, 1, 2), (8, 40, 40, 384, 256, 1, 1), (8, 40, 40, 384, 384, 3, 2),
+           (8, 40, 40, 384, 384, 1, 2), (8, 20, 20, 384, 384, 3, 2), (8, 20, 20, 384, 384, 1, 2),
+           (8, 10, 10, 384, 512, 3, 2), (8, 10, 10, 384, 512, 1, 2), (8, 5, 5, 512, 384, 1, 1),
+           (8, 160, 160, 256, 64, 1, 1)]
+
 _flush = None
 
 
@@ -53,7 +61,10 @@ def main():
     ap.add_argument('--plans', default='', help='comma list of "bm:ksplit" overrides to sweep, e.g. 64:4,64:8,128:2')
     ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--stamps', action='store_true', help='print in-kernel timeline (us) of one cold launch per plan')
+    ap.add_argument('--conv2d', action='store_true', help='og_conv2d_bf16 on the 1x1 / stride-2 shapes instead')
     a = ap.parse_args()
+    if a.conv2d:
+        return main_conv2d(a)
     dev = torch.device('cuda:0')
     lib = _lib.load()
     torch.backends.cudnn.benchmark = True
@@ -123,6 +134,61 @@ def main():
                         import numpy as np
                         print(f'      {nm:11s} {np.median(col):7.2f} {col.max():7.2f}   (n={len(col)})')
             t = graph_time(ours, a.reps)
+            line += f' | {plan or "auto"}: {t:6.1f} us ({gflop / t * 1e-3:5.0f} TF) err {err:.1e}'
+        print(line, flush=True)
+
+
+def main_conv2d(a):
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(0)
+    cl = torch.channels_last
+    for si, (n, h, w, cin, cout, k, st) in enumerate(SHAPES2):
+        if a.only and si not in a.only:
+            continue
+        reps = a.reps if n * h * w * cin < (1 << 24) else max(3, a.reps // 4)
+        xs = [torch.randn(n, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(reps)]
+        wts = [(torch.randn(cout, cin, k, k, device=dev) * (1.0 / (k * k * cin)) ** 0.5).to(torch.bfloat16)
+               .contiguous(memory_format=cl) for _ in range(reps)]
+        bias = torch.randn(cout, device=dev) * 0.1
+        ref = F.relu(F.conv2d(xs[-1].float(), wts[-1].float(), bias, st, k // 2))
+        ho, wo = ref.shape[2:]
+        out = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
+        need = lib.og_conv2d_workspace_bytes(n, h, w, cin, cout, k, st)
+        ws = torch.zeros(max(need, 256) * 8 + (1 << 20), dtype=torch.uint8, device=dev)
+
+        def ours(l=-1):
+            _lib.check(lib.og_conv2d_bf16(_lib.ptr(xs[l]), _lib.ptr(wts[l]), _lib.ptr(bias), None, _lib.ptr(out),
+                                          n, h, w, cin, cout, k, st, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+
+        def miopen_raw(l=-1):
+            return F.conv2d(xs[l], wts[l], None, st, k // 2)
+
+        def miopen(l=-1):
+            y = F.conv2d(xs[l], wts[l], None, st, k // 2)
+            _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias), None, n * ho * wo, cout, 1,
+                                            _lib.stream_ptr(dev)), lib)
+            return y
+
+        t_raw = graph_time(miopen_raw, reps)
+        t_ref = graph_time(miopen, reps)
+        gflop = 2 * n * ho * wo * cout * k * k * cin / 1e9
+        line = f'[{si}] {n}x{h}x{w} {cin}->{cout} k{k} s{st} ({gflop:.2f} GF): miopen {t_raw:7.1f} +epilogue {t_ref:7.1f} us'
+        for plan in [''] + [p for p in a.plans.split(',') if p]:
+            if plan:
+                os.environ['OG_CONV_PLAN'] = plan.replace(':', ',')
+            else:
+                os.environ.pop('OG_CONV_PLAN', None)
+            out.zero_()
+            try:
+                ours()
+            except Exception as ex:  # noqa: BLE001
+                line += f' | {plan or "auto"}: {str(ex)[-50:]}'
+                continue
+            torch.cuda.synchronize()
+            err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            t = graph_time(ours, reps)
             line += f' | {plan or "auto"}: {t:6.1f} us ({gflop / t * 1e-3:5.0f} TF) err {err:.1e}'
         print(line, flush=True)
 
