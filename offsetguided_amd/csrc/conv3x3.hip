@@ -574,7 +574,7 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9)
     p.bm = p.bn = bm;
     p.stages = bm == 128 ? 3 : 4;
     if (steps < 3) p.stages = 3;  // 1x1 convolutions with Cin = 128: two K steps
-    if (force_stages == 4 || force_stages == 3 || (force_stages == 8 && bm == 64)) p.stages = force_stages;
+    if (force_stages == 4 || force_stages == 3 || ((force_stages == 8 || force_stages == 2) && bm == 64)) p.stages = force_stages;
     p.m_tiles = (int)((M + bm - 1) / bm);
     p.n_tiles = Cout / bm;
     // per layer inside the network (rocprofv3, conv + finish, us): 20x20 ks 2/3/6/9 = 34.9/31.4/36.2/41.1,
@@ -736,6 +736,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     else if (p.bm == 128) CONV_LAUNCH(128, 3);
     else if (p.stages == 8) CONV_LAUNCH(64, 8);
     else if (p.stages == 3) CONV_LAUNCH(64, 3);
+    else if (p.stages == 2) CONV_LAUNCH(64, 2);
     else CONV_LAUNCH(64, 4);
 #undef CONV_LAUNCH
     if (p.ksplit > 1 && !p.in_launch) {
