@@ -210,6 +210,15 @@ int og_conv2d_bf16(const void *x, const void *w, const float *bias, const void *
                    int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes,
                    void *stream);
 size_t og_conv2d_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride);
+/* A whole projection residual tail in one launch: out = act(conv(x) + conv1x1(x2, stride2) + bias) -- residual.forward
+ * models/hourglass_104.py:70-79 with the `skip` branch (:63-68) a 1x1 convolution + BN: bn2(conv2(.)) + skip(x), ReLU.
+ * The projection is appended along K: w_cat (Cout, ksize*ksize*Cin + Cin2) = [conv weight (Cout,k,k,Cin) | projection
+ * weight (Cout,Cin2)], x2 (N,H2,W2,Cin2) sampled at (y*stride2, x*stride2); bias = the sum of both folded biases.
+ * Always the split-K kernel (meant for the small levels); workspace: og_conv2d_proj_workspace_bytes. */
+int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,
+                        int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2, int stride2, int relu,
+                        void *workspace, size_t workspace_bytes, void *stream);
+size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int Cin2);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 void og_conv3x3_debug_stamps(void *buf);

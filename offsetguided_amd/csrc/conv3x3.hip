@@ -50,6 +50,10 @@ struct ConvArgs {
     int N, H, W, Cin, Cout, M;   // H, W = OUTPUT height / width; M = N*H*W output pixels
     int Hin, Win, stride, taps;  // input height / width, stride 1|2, taps 9 (3x3, pad 1) | 1 (1x1, pad 0)
     int n_tiles, steps_per_split, ksplit, relu;
+    // optional 1x1 projection of a second tensor, summed into the same accumulators (residual.skip): K steps
+    // steps_main .. steps_total-1 read x2 (N,H2,W2,Cin2) at (y*stride2, x*stride2); w rows are [taps*Cin | Cin2] wide
+    const unsigned short *x2;
+    int Cin2, H2, W2, stride2, steps_main, steps_total, w_row;
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
@@ -135,13 +139,13 @@ conv3x3_kernel(ConvArgs a)
     const int m_tile = blockIdx.x / a.n_tiles, n_tile = blockIdx.x % a.n_tiles, split = blockIdx.y;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int step0 = split * a.steps_per_split;
-    const int nsteps = a.steps_per_split;
+    const int nsteps = min(a.steps_per_split, a.steps_total - step0);   // the last split may be shorter
     const int chunks = a.Cin >> 6;                  // K steps per tap
 
     // ---- loader set-up: piece p = tid + 256*i -> tile row p/8, LDS slot p%8, source chunk slot^((row>>1)&7)
     // output pixel m -> centre input pixel (y*stride, x*stride); a 3x3 tap adds (dy, dx) in -1..1, a 1x1 conv has the
     // centre tap only (pad 0)
-    const unsigned short *px_ptr[PX];
+    const unsigned short *px_ptr[PX], *px2_ptr[PX];
     uint32_t px_mask[PX];
     const int taps = a.taps;
 #pragma unroll
@@ -163,25 +167,34 @@ conv3x3_kernel(ConvArgs a)
         }
         px_mask[i] = mask;
         px_ptr[i] = a.x + (m < a.M ? ((size_t)img * a.Hin + yc) * a.Win + xc : (size_t)0) * a.Cin + c * 8;
+        px2_ptr[i] = (a.x2 && m < a.M)
+                         ? a.x2 + (((size_t)img * a.H2 + y * a.stride2) * a.W2 + xw * a.stride2) * a.Cin2 + c * 8
+                         : a.zero;
     }
     const unsigned short *w_ptr[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_ptr[i] = a.w + (size_t)(n0 + r) * taps * a.Cin + c * 8;
+        w_ptr[i] = a.w + (size_t)(n0 + r) * a.w_row + c * 8;
     }
     const int lds_piece = (wave * 64) * 16;  // wave-uniform; + lane*16 is implied by the DMA
 
     auto issue = [&](int step_local, int buf) {
         const int step = step0 + step_local;
-        const int tap = step / chunks, ci0 = (step - tap * chunks) << 6;
-        const int dy = taps == 1 ? 0 : tap / 3 - 1, dx = taps == 1 ? 0 : tap - (tap / 3) * 3 - 1;
-        const long shift = ((long)dy * a.Win + dx) * a.Cin + ci0;
         unsigned char *base = lds + buf * kStage + lds_piece;
+        if (step < a.steps_main) {
+            const int tap = step / chunks, ci0 = (step - tap * chunks) << 6;
+            const int dy = taps == 1 ? 0 : tap / 3 - 1, dx = taps == 1 ? 0 : tap - (tap / 3) * 3 - 1;
+            const long shift = ((long)dy * a.Win + dx) * a.Cin + ci0;
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            const unsigned short *src = (px_mask[i] >> tap) & 1 ? px_ptr[i] + shift : a.zero;
-            glds16(src, base + i * 4096);
+            for (int i = 0; i < PX; ++i) {
+                const unsigned short *src = (px_mask[i] >> tap) & 1 ? px_ptr[i] + shift : a.zero;
+                glds16(src, base + i * 4096);
+            }
+        } else {
+            const int ci0 = (step - a.steps_main) << 6;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) glds16(px_mask[i] ? px2_ptr[i] + ci0 : a.zero, base + i * 4096);
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) glds16(w_ptr[i] + (size_t)step * 64, base + BM * kRowB + i * 4096);
@@ -563,9 +576,9 @@ struct Plan {
 
 // Tile and K split.  Measured inside the network (bs8, tools/bb_bench.py, whole-forward ms): 64-wide tiles with
 // ~6 K splits 10.82, 64/3 10.89, shape-dependent 128-wide tiles 11.15, 128/3 11.85, no split 11.82; MIOpen 11.59.
-bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9)
+bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps = 0)
 {
-    const int steps = taps * Cin / 64;
+    const int steps = taps * Cin / 64 + extra_steps;
     const char *e = getenv("OG_CONV_PLAN");  // "bm,ksplit,stages" override for tuning
     int bm = 64, force_split = 0, force_stages = 0;
     if (e) sscanf(e, "%d,%d,%d", &bm, &force_split, &force_stages);
@@ -584,10 +597,15 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9)
     int best = 1;
     for (int ks = 2; ks <= max_ks; ++ks)
         if (steps % ks == 0 && steps / ks >= 4 && steps / ks >= p.stages - 1) best = ks;
+    if (extra_steps && best < max_ks)  // K with a projection appended rarely divides: allow a shorter last split
+        for (int ks = best + 1; ks <= max_ks; ++ks) {
+            const int sps = (steps + ks - 1) / ks, last = steps - (ks - 1) * sps;
+            if (sps >= 4 && last >= p.stages - 1 && last >= 1) best = ks;
+        }
     if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
     if (steps < p.stages - 1) return false;
     p.ksplit = best;
-    p.steps_per_split = steps / best;
+    p.steps_per_split = (steps + best - 1) / best;
     // In-launch reduction (last arriver, one batch of sc1 loads) vs a finish kernel, per layer inside the network:
     // 20x20 30.1 vs 32.0 us, 10x10 14.4 vs 15.9, 5x5 13.4 vs 13.1.  (With 128-wide tiles and 6 splits the in-launch
     // form lost at 20x20, 39.9 vs 34.2: slab bytes per last arriver decide.)
@@ -649,14 +667,29 @@ OG_API size_t og_conv2d_workspace_bytes(int N, int Hin, int Win, int Cin, int Co
     return ws_layout(p, nullptr, nullptr);
 }
 
+OG_API size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int Cin2)
+{
+    if (N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || Cin2 <= 0 || Cin2 % 64) return 0;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    const long M = (long)N * conv_out_dim(Hin, ksize, stride) * conv_out_dim(Win, ksize, stride);
+    Plan p;
+    if (!make_plan(M, Cin, Cout, p, ksize * ksize, Cin2 / 64)) return 0;
+    return ws_layout(p, nullptr, nullptr);
+}
+
 OG_API size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int Cout)
 {
     return og_conv2d_workspace_bytes(N, H, W, Cin, Cout, 3, 1);
 }
 
+struct Proj {  // optional second operand: out += conv1x1(x2, stride2), weights appended along K
+    const void *x2 = nullptr;
+    int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
+};
+
 static int conv_run(const char *name, const void *x, const void *w, const float *bias, const void *skip, void *out, int N,
                     int Hin, int Win, int Cin, int Cout, int ksize, int stride, int relu, void *workspace,
-                    size_t workspace_bytes, void *stream)
+                    size_t workspace_bytes, void *stream, const Proj &pj = Proj())
 {
     OG_REQUIRE(x && w && bias && out && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && Hin > 0 && Win > 0, OG_EINVAL, "%s: bad shape", name);
@@ -670,7 +703,14 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
                "%s: tensor too large (>= 2 GiB)", name);
     OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
     hipStream_t st = (hipStream_t)stream;
-    if (const int kind = (ksize == 3 && stride == 1) ? halo_kind(M, H, W, Cin, Cout) : 0) {
+    if (pj.x2) {
+        OG_REQUIRE(pj.Cin2 > 0 && pj.Cin2 % 64 == 0 && (pj.stride2 == 1 || pj.stride2 == 2), OG_EUNSUPPORTED,
+                   "%s: projection needs Cin2 %% 64 == 0 and stride 1|2 (got %d, %d)", name, pj.Cin2, pj.stride2);
+        OG_REQUIRE(conv_out_dim(pj.H2, 1, pj.stride2) == H && conv_out_dim(pj.W2, 1, pj.stride2) == W, OG_EINVAL,
+                   "%s: projection input %dx%d / stride %d does not give the %dx%d output", name, pj.H2, pj.W2, pj.stride2, H, W);
+        OG_REQUIRE((long)N * pj.H2 * pj.W2 * pj.Cin2 < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
+    }
+    if (const int kind = (ksize == 3 && stride == 1 && !pj.x2) ? halo_kind(M, H, W, Cin, Cout) : 0) {
         ConvArgs h = {};
         h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
         h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
@@ -699,7 +739,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
         return OG_OK;
     }
     Plan p;
-    OG_REQUIRE(make_plan(M, Cin, Cout, p, taps), OG_EUNSUPPORTED, "%s: no tile plan", name);
+    OG_REQUIRE(make_plan(M, Cin, Cout, p, taps, pj.x2 ? pj.Cin2 / 64 : 0), OG_EUNSUPPORTED, "%s: no tile plan", name);
     OG_REQUIRE((size_t)p.m_tiles * p.n_tiles <= kMaxTiles, OG_EUNSUPPORTED, "%s: too many tiles", name);
     const size_t need = ws_layout(p, nullptr, nullptr);
     OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu bytes", name, workspace_bytes, need);
@@ -717,6 +757,11 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     a.partial = (float *)((char *)workspace + s_off);
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = (int)M;
     a.Hin = Hin; a.Win = Win; a.stride = stride; a.taps = taps;
+    a.x2 = (const unsigned short *)pj.x2;
+    a.Cin2 = pj.x2 ? pj.Cin2 : 0; a.H2 = pj.H2; a.W2 = pj.W2; a.stride2 = pj.stride2;
+    a.steps_main = taps * Cin / 64;
+    a.steps_total = a.steps_main + a.Cin2 / 64;
+    a.w_row = taps * Cin + a.Cin2;
     a.stamps = g_stamps;
     a.in_launch_reduce = p.in_launch;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
@@ -762,4 +807,15 @@ OG_API int og_conv2d_bf16(const void *x, const void *w, const float *bias, const
 {
     return conv_run("og_conv2d_bf16", x, w, bias, skip, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
                     workspace_bytes, stream);
+}
+
+OG_API int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N,
+                               int Hin, int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2,
+                               int stride2, int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    OG_REQUIRE(x2, OG_EINVAL, "og_conv2d_proj_bf16: null pointer");
+    Proj pj;
+    pj.x2 = x2; pj.H2 = H2; pj.W2 = W2; pj.Cin2 = Cin2; pj.stride2 = stride2;
+    return conv_run("og_conv2d_proj_bf16", x, w_cat, bias, nullptr, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
+                    workspace_bytes, stream, pj);
 }

@@ -128,13 +128,38 @@ class _Residual:
         self.c1 = _Conv(m.conv1, m.bn1, True, dtype, fused)
         self.c2 = _Conv(m.conv2, m.bn2, True, dtype, fused)       # ReLU after the residual sum
         self.skip = _Conv(m.skip[0], m.skip[1], False, dtype, fused) if len(m.skip) else None
+        self.w_cat = None
         if self.skip is not None:  # the projection's bias rides on conv2's epilogue
             self.c2.b32 = (self.c2.b32 + self.skip.b32).contiguous()
             self.c2.b = self.c2.b32.to(dtype)
+            # small levels: the 1x1 projection is appended along K of conv2 (og_conv2d_proj_bf16), one launch instead
+            # of a MIOpen convolution + its output round trip
+            if (self.c2.hip3x3 and tuple(self.c2.stride) == (1, 1) and tuple(self.skip.w.shape[2:]) == (1, 1)
+                    and self.skip.w.shape[1] % 64 == 0 and int(os.environ.get('OG_ENGINE_CONV_PROJ', '1'))):
+                cout = self.c2.w.shape[0]
+                self.w_cat = torch.cat([self.c2.w.permute(0, 2, 3, 1).reshape(cout, -1),
+                                        self.skip.w.reshape(cout, -1)], 1).contiguous()
 
     def __call__(self, x):
+        y = self.c1(x)
+        n, c, h, w = y.shape
+        if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS:
+            return self._proj(y, x)
         shortcut = x if self.skip is None else self.skip.raw(x)
-        return self.c2(self.c1(x), skip=shortcut)
+        return self.c2(y, skip=shortcut)
+
+    def _proj(self, y, x):
+        n, c, h, w = y.shape
+        _, c2, h2, w2 = x.shape
+        cout, st2 = self.c2.w.shape[0], self.skip.stride[0]
+        assert y.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)
+        lib = _lib.load()
+        out = torch.empty((n, cout, h, w), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
+        ws = _conv3x3_workspace(y.device, lib.og_conv2d_proj_workspace_bytes(n, h, w, c, cout, 3, 1, c2))
+        _lib.check(lib.og_conv2d_proj_bf16(_lib.ptr(y), _lib.ptr(self.w_cat), _lib.ptr(self.c2.b32), _lib.ptr(x), _lib.ptr(out),
+                                           n, h, w, c, cout, 3, 1, h2, w2, c2, st2, 1, _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(y.device)), lib)
+        return out
 
 
 def _seq(mods, dtype, fused):

@@ -112,6 +112,40 @@ def test_conv2d_matches_torch(dev, shape):
     assert ws[:256].count_nonzero().item() == 0
 
 
+@pytest.mark.parametrize("shape", [(8, 5, 5, 384, 384, 512, 1), (8, 5, 5, 512, 512, 384, 2), (8, 10, 10, 384, 384, 384, 2),
+                                   (2, 20, 20, 384, 384, 384, 2), (3, 7, 9, 64, 128, 192, 1), (2, 9, 6, 128, 64, 64, 2)])
+def test_conv2d_proj_matches_torch(dev, shape):
+    """og_conv2d_proj_bf16 = relu(conv3x3(y) + conv1x1(x, stride) + bias), the tail of a projection residual
+    (models/hourglass_104.py:70-79), vs fp32 torch convolutions of the same bf16 operands."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout, cin2, st2 = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 100 + cin2 + st2)
+    cl = torch.channels_last
+    y = torch.randn(n, cin, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    h2, w2 = (h, w) if st2 == 1 else (2 * h - 1, 2 * w)           # odd and even input sizes both give h x w at stride 2
+    x = torch.randn(n, cin2, h2, w2, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    wp = (torch.randn(cout, cin2, 1, 1, generator=g) * (1.0 / cin2) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    ref = F.relu(F.conv2d(y.float(), wt.float(), bias, 1, 1) + F.conv2d(x.float(), wp.float(), None, st2, 0))
+    assert tuple(ref.shape[2:]) == (h, w)
+    w_cat = torch.cat([wt.permute(0, 2, 3, 1).reshape(cout, -1), wp.reshape(cout, -1)], 1).contiguous()
+    need = lib.og_conv2d_proj_workspace_bytes(n, h, w, cin, cout, 3, 1, cin2)
+    assert need > 0
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    out = torch.full((n, cout, h, w), float('nan'), dtype=torch.bfloat16, device=dev).contiguous(memory_format=cl)
+    for _ in range(2):
+        _lib.check(lib.og_conv2d_proj_bf16(_lib.ptr(y), _lib.ptr(w_cat), _lib.ptr(bias), _lib.ptr(x), _lib.ptr(out), n, h, w,
+                                           cin, cout, 3, 1, h2, w2, cin2, st2, 1, _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(dev)), lib)
+    err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 6e-3, f'relative error {err}'
+    rc = lib.og_conv2d_proj_bf16(_lib.ptr(y), _lib.ptr(w_cat), _lib.ptr(bias), _lib.ptr(x), _lib.ptr(out), n, h, w, cin, cout,
+                                 3, 1, h2 + 4, w2, cin2, st2, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    assert rc == _lib.OG_EINVAL                                   # projection input that does not map onto the output
+
+
 def test_conv2d_rejects_bad_arguments(dev):
     lib = _lib.load()
     x = _nhwc(1, 64, 8, 8, dev=dev)
