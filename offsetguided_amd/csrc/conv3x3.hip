@@ -297,7 +297,11 @@ conv3x3_kernel(ConvArgs a)
         if (!*flag) return;
         // all loads of a batch are issued before the first add (one memory round trip per batch, not per slab);
         // the own slab and slots past ksplit are read out of range, which a buffer load returns as 0
-        constexpr int kBatch = NT * MT >= 16 ? 1 : 16 / (NT * MT);
+        // (64-wide tiles: 8 slabs = every plan's K split in ONE round trip; two dependent batches cost 2 us per layer)
+#ifndef OG_GATHER_SLABS
+#define OG_GATHER_SLABS 32
+#endif
+        constexpr int kBatch = NT * MT >= 16 ? 1 : OG_GATHER_SLABS / (NT * MT);
         for (int sp0 = 0; sp0 < a.ksplit; sp0 += kBatch) {
             f32x4 part[kBatch][NT * MT];
 #pragma unroll
