@@ -28,6 +28,8 @@ import time
 
 # One MIOpen user database per rank: with N ranks on a node every process runs MIOpen's kernel search while the engine
 # is built, and they would otherwise all write the same sqlite files under ~/.config/miopen.
+# the engine's HIP graph replays its branches on the runtime's hardware queues; 4 (the default) measured best
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
 if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
     _db = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'miopen_rank%s' % os.environ.get('LOCAL_RANK', '0'))
     os.makedirs(_db, exist_ok=True)
@@ -56,6 +58,8 @@ def parse():
     ap.add_argument('--flip', action='store_true', help='flip-test (BASELINE config 3): 2x images through the backbone')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--inflight', type=int, default=1,
+                    help='batches in flight: >1 builds that many engines + decoders, each on its own HIP stream')
     ap.add_argument('--overlap', action='store_true',
                     help='run the decoder on a second HIP stream beside the next backbone (measured: no gain, the\n'
                          'backbone already saturates the chip, and K1 then competes with the convolutions for HBM)')
@@ -107,9 +111,11 @@ def main():
     model, _ = models.model_factory(margs)
     bench_init(model, 1234)
     nb = a.batch * (2 if a.flip else 1)
-    engine = models.InferenceEngine(model, nb, a.size, a.size, dtype=torch.bfloat16, device=dev,
-                                    use_graph=not a.no_graph)
-    proc = decoder.decoder_factory(margs)
+    engines = [models.InferenceEngine(model, nb, a.size, a.size, dtype=torch.bfloat16, device=dev,
+                                      use_graph=not a.no_graph) for _ in range(a.inflight)]
+    procs = [decoder.decoder_factory(margs) for _ in range(a.inflight)]
+    engine, proc = engines[0], procs[0]
+    lanes = [torch.cuda.Stream(dev) for _ in range(a.inflight)] if a.inflight > 1 else None
 
     # ---- synthetic inputs, resident in HBM ----
     n_rot = 3
@@ -120,7 +126,7 @@ def main():
         hm, off = synth.synth_batch(1000 * rank + r, a.batch, a.size, a.size, flip=a.flip)
         maps.append((torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev), hm, off))
 
-    def features(i):
+    def features(i, engine=engine):
         hm_o, off_o = engine.forward_raw(images[i % n_rot])
         hm_s, off_s = maps[i % n_rot][0], maps[i % n_rot][1]
         hm, off = hm_o + hm_s, off_o + off_s
@@ -135,6 +141,8 @@ def main():
     def run_steps(n, first=0):
         """Backbone on the main stream; the decoder of batch i on a second stream, so it overlaps the
         backbone of batch i+1 (HIP streams, event-ordered; no host sync besides the pose pick-up)."""
+        if lanes is not None:
+            return run_steps_lanes(n, first)
         pending, out = None, None
         for i in range(first, first + n):
             feats = features(i)
@@ -150,6 +158,23 @@ def main():
                 out = pending.result()
             pending = nxt
         out = pending.result()
+        torch.cuda.synchronize(dev)
+        return out
+
+    def run_steps_lanes(n, first=0):
+        """--inflight L: batch i runs whole (backbone graph + decoder) on lane i % L; the host picks up batch i - L."""
+        pending, out = [], None
+        for ln in lanes:
+            ln.wait_stream(main_stream)
+        for i in range(first, first + n):
+            j = i % a.inflight
+            with torch.cuda.stream(lanes[j]):
+                nxt = procs[j].submit(features(i, engines[j]), flip_test=a.flip)
+            pending.append(nxt)
+            if len(pending) > a.inflight:
+                out = pending.pop(0).result()
+        while pending:
+            out = pending.pop(0).result()
         torch.cuda.synchronize(dev)
         return out
 

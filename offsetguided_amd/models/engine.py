@@ -64,12 +64,14 @@ CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192
 BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 _conv_ws = {}
 _branch = 0      # which concurrent branch is issuing work: 0 = trunk, d+1 = up1 branch of level d
+_engine = 0      # which InferenceEngine is issuing work (engines may run concurrently on different streams)
+_n_engines = 0
 
 
 def _conv3x3_workspace(device, nbytes):
     """One zero-initialised scratch per (device, concurrent branch) for og_conv3x3_bf16 (zero page + split-K slabs).
     Layers of one branch run back to back on one stream, so they share it; it only ever grows outside graph capture."""
-    key = (device.index, _branch)
+    key = (device.index, _engine, _branch)
     buf = _conv_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         assert not torch.cuda.is_current_stream_capturing(), 'conv3x3 workspace must be sized before graph capture'
@@ -220,6 +222,9 @@ class InferenceEngine:
     def __init__(self, model, batch, height, width, dtype=torch.bfloat16, device='cuda:0', feat_stage=-1,
                  use_graph=True):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
+        global _n_engines
+        self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
+        _n_engines += 1
         self.device = torch.device(device)
         self.dtype = dtype
         self.shape = (batch, 3, height, width)
@@ -279,6 +284,8 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
+        global _engine
+        _engine = self._id
         if self.stem_w is not None:   # fused stem: fp32 NCHW images -> conv 7x7 s2 + BN + ReLU -> bf16 NHWC
             lib = _lib.load()
             images = images.float().contiguous()
