@@ -62,6 +62,7 @@ CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
 BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
+BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fork up1 only at levels <= this depth
 _conv_ws = {}
 _branch = 0      # which concurrent branch is issuing work: 0 = trunk, d+1 = up1 branch of level d
 _engine = 0      # which InferenceEngine is issuing work (engines may run concurrently on different streams)
@@ -188,7 +189,7 @@ class _Level:
 
     def __call__(self, x):
         global _branch
-        if BRANCHES and x.is_cuda:
+        if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None:
                 # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work
