@@ -30,6 +30,7 @@ import time
 # is built, and they would otherwise all write the same sqlite files under ~/.config/miopen.
 # the engine's HIP graph replays its branches on the runtime's hardware queues; 4 (the default) measured best
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory (see offsetguided_amd/__init__.py)
 if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
     _db = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'miopen_rank%s' % os.environ.get('LOCAL_RANK', '0'))
     os.makedirs(_db, exist_ok=True)

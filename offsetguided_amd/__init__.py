@@ -1,0 +1,7 @@
+"""OffsetGuided inference hot path on MI355X: HIP decoder kernels + bf16 HIP-graph backbone behind the reference's API."""
+import os
+
+# Kernel arguments in device memory instead of host-coherent memory: every kernel of the captured forward starts
+# ~1.5 us earlier (171 launches: 7.53 -> 7.23 ms per bs8 forward).  Read by the HIP runtime when it initialises, so it
+# only takes effect if this package is imported before the first GPU call; an explicit setting by the caller wins.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')

@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--plans', default='', help='comma list of "bm:ksplit" overrides to sweep, e.g. 64:4,64:8,128:2')
     ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--stamps', action='store_true', help='print in-kernel timeline (us) of one cold launch per plan')
+    ap.add_argument('--warm', action='store_true', help='no cache flush between timed replays (weights stay in the Infinity Cache)')
     ap.add_argument('--conv2d', action='store_true', help='og_conv2d_bf16 on the 1x1 / stride-2 shapes instead')
     a = ap.parse_args()
     if a.conv2d:
@@ -93,7 +94,7 @@ def main():
                                             _lib.stream_ptr(dev)), lib)
             return y
 
-        t_ref = graph_time(miopen, a.reps)
+        t_ref = graph_time(miopen, a.reps, cold=not a.warm)
         gflop = 2 * n * h * w * cout * 9 * cin / 1e9
         line = f'{n}x{h}x{w} {cin}->{cout} ({gflop:.2f} GF): miopen+epilogue {t_ref:7.1f} us'
         for plan in [''] + [p for p in a.plans.split(',') if p]:
@@ -133,7 +134,7 @@ def main():
                     if len(col):
                         import numpy as np
                         print(f'      {nm:11s} {np.median(col):7.2f} {col.max():7.2f}   (n={len(col)})')
-            t = graph_time(ours, a.reps)
+            t = graph_time(ours, a.reps, cold=not a.warm)
             line += f' | {plan or "auto"}: {t:6.1f} us ({gflop / t * 1e-3:5.0f} TF) err {err:.1e}'
         print(line, flush=True)
 
