@@ -139,6 +139,50 @@ def int_table(values, device):
 
 # ---- optional per-stage device timing (bench.py) -------------------------------------------
 _profile = None  # dict name -> list of (start_event, end_event) while enabled
+_hip = None
+
+
+def _hip_runtime():
+    """The HIP runtime torch already loaded (same streams / events), for the calls torch does not expose."""
+    global _hip
+    if _hip is None:
+        paths = [l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l]
+        if not paths:
+            raise OgError('libamdhip64 is not loaded: no HIP device runtime in this process')
+        _hip = C.CDLL(paths[0])
+    return _hip
+
+
+class TimingEvent:
+    """HIP event for timing only, created with hipEventDisableSystemFence: a default event performs a system-scope
+    fence (L2 write-back + invalidate) when it is recorded, ~5 us each on the stream it times and a cold L2 for the
+    kernel behind it.  elapsed_time() needs the stream (or device) synchronised first."""
+    DISABLE_SYSTEM_FENCE = 0x20000000
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        rc = _hip_runtime().hipEventCreateWithFlags(C.byref(self.h), C.c_uint(self.DISABLE_SYSTEM_FENCE))
+        if rc != 0:
+            raise OgError(f'hipEventCreateWithFlags failed ({rc})')
+
+    def record(self, stream):
+        rc = _hip_runtime().hipEventRecord(self.h, C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise OgError(f'hipEventRecord failed ({rc})')
+
+    def elapsed_time(self, end):
+        ms = C.c_float()
+        rc = _hip_runtime().hipEventElapsedTime(C.byref(ms), self.h, end.h)
+        if rc != 0:
+            raise OgError(f'hipEventElapsedTime failed ({rc})')
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h and _hip is not None:
+                _hip.hipEventDestroy(self.h)
+        except Exception:  # noqa: BLE001  interpreter shutdown
+            pass
 
 
 class stage_timer:
@@ -150,12 +194,12 @@ class stage_timer:
 
     def __enter__(self):
         if _profile is not None:
-            self.start = torch.cuda.Event(enable_timing=True)
+            self.start = TimingEvent()
             self.start.record(torch.cuda.current_stream(self.device))
 
     def __exit__(self, *exc):
         if _profile is not None:
-            end = torch.cuda.Event(enable_timing=True)
+            end = TimingEvent()
             end.record(torch.cuda.current_stream(self.device))
             _profile.setdefault(self.name, []).append((self.start, end))
 
