@@ -58,6 +58,7 @@ struct ConvArgs {
     // steps_main .. steps_total-1 read x2 (N,H2,W2,Cin2) at (y*stride2, x*stride2); w rows are [taps*Cin | Cin2] wide
     const unsigned short *x2;
     int Cin2, H2, W2, stride2, steps_main, steps_total, w_row;
+    uint32_t magic_w, magic_h, magic_chunks;   // ceil(2^32 / d) for d = W, H, Cin/64 (0 when d == 1): q = umulhi(n, magic)
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
@@ -98,6 +99,10 @@ __device__ __forceinline__ void wait_vm_lgkm0()
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
 }
+
+// n / d for the divisors a launch fixes (d*n < 2^32): one v_mul_hi instead of the ~25-instruction software division --
+// the per-piece set-up and the per-step tap arithmetic of the split-K kernel are latency, not throughput.
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }
 
 // Epilogue of one BM x BN tile: lane holds couts co..co+3 of pixel pm in acc[n][m].
 template <int BM, int BN>
@@ -156,17 +161,15 @@ conv3x3_kernel(ConvArgs a)
     for (int i = 0; i < PX; ++i) {
         const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
         const int m = m0 + r;
-        const int xw = m % a.W, t = m / a.W, y = t % a.H, img = t / a.H;
+        const int t = (int)div_magic((uint32_t)m, a.magic_w), xw = m - t * a.W;
+        const int img = (int)div_magic((uint32_t)t, a.magic_h), y = t - img * a.H;
         const int yc = y * a.stride, xc = xw * a.stride;
         uint32_t mask = 0;
         if (m < a.M) {
             if (taps == 1) mask = 1u;
-            else {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int yy = yc + tap / 3 - 1, xx = xc + tap % 3 - 1;
-                    if (yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win) mask |= 1u << tap;
-                }
+            else {   // separable: 3 valid columns x 3 valid rows
+                const uint32_t cols = (xc >= 1 ? 1u : 0u) | 2u | (xc + 1 < a.Win ? 4u : 0u);
+                mask = (yc >= 1 ? cols : 0u) | (cols << 3) | (yc + 1 < a.Hin ? cols << 6 : 0u);
             }
         }
         px_mask[i] = mask;
@@ -175,33 +178,47 @@ conv3x3_kernel(ConvArgs a)
                          ? a.x2 + (((size_t)img * a.H2 + y * a.stride2) * a.W2 + xw * a.stride2) * a.Cin2 + c * 8
                          : a.zero;
     }
-    const unsigned short *w_ptr[PW];
+    const unsigned short *w_ptr[PW];   // advanced by one K step (64 elements) per issue
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = tid + 256 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_ptr[i] = a.w + (size_t)(n0 + r) * a.w_row + c * 8;
+        w_ptr[i] = a.w + (size_t)(n0 + r) * a.w_row + c * 8 + (size_t)step0 * 64;
     }
     const int lds_piece = (wave * 64) * 16;  // wave-uniform; + lane*16 is implied by the DMA
 
-    auto issue = [&](int step_local, int buf) {
-        const int step = step0 + step_local;
+    // K steps are issued strictly in order, so (tap, channel offset, tap shift) are running scalars: no division
+    int i_step = step0;
+    int i_tap = (int)div_magic((uint32_t)step0, a.magic_chunks), i_ci = (step0 - i_tap * chunks) << 6;
+    int i_dy = taps == 1 ? 0 : (i_tap * 11 >> 5) - 1;                      // tap / 3 for tap < 9
+    int i_dx = taps == 1 ? 0 : i_tap - (i_dy + 1) * 3 - 1;
+    long i_shift = ((long)i_dy * a.Win + i_dx) * a.Cin;
+    auto issue = [&](int buf) {
         unsigned char *base = lds + buf * kStage + lds_piece;
-        if (step < a.steps_main) {
-            const int tap = step / chunks, ci0 = (step - tap * chunks) << 6;
-            const int dy = taps == 1 ? 0 : tap / 3 - 1, dx = taps == 1 ? 0 : tap - (tap / 3) * 3 - 1;
-            const long shift = ((long)dy * a.Win + dx) * a.Cin + ci0;
+        if (i_step < a.steps_main) {
+            const long shift = i_shift + i_ci;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                const unsigned short *src = (px_mask[i] >> tap) & 1 ? px_ptr[i] + shift : a.zero;
+                const unsigned short *src = (px_mask[i] >> i_tap) & 1 ? px_ptr[i] + shift : a.zero;
                 glds16(src, base + i * 4096);
             }
+            i_ci += 64;
+            if (i_ci == a.Cin) {
+                i_ci = 0;
+                ++i_tap;
+                if (++i_dx > 1) { i_dx = -1; ++i_dy; }
+                i_shift = ((long)i_dy * a.Win + i_dx) * a.Cin;
+            }
         } else {
-            const int ci0 = (step - a.steps_main) << 6;
+            const int ci0 = (i_step - a.steps_main) << 6;
 #pragma unroll
             for (int i = 0; i < PX; ++i) glds16(px_mask[i] ? px2_ptr[i] + ci0 : a.zero, base + i * 4096);
         }
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(w_ptr[i] + (size_t)step * 64, base + BM * kRowB + i * 4096);
+        for (int i = 0; i < PW; ++i) {
+            glds16(w_ptr[i], base + BM * kRowB + i * 4096);
+            w_ptr[i] += 64;
+        }
+        ++i_step;
     };
 
     // ---- compute set-up
@@ -228,7 +245,7 @@ conv3x3_kernel(ConvArgs a)
 
     // ---- prologue: STAGES-1 steps in flight (the host guarantees nsteps >= STAGES-1)
 #pragma unroll
-    for (int j = 0; j < STAGES - 1; ++j) issue(j, j);
+    for (int j = 0; j < STAGES - 1; ++j) issue(j);
     CONV_STAMP(1);
 
     int buf = 0, nbuf = STAGES - 1;
@@ -238,7 +255,7 @@ conv3x3_kernel(ConvArgs a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s == 0) CONV_STAMP(2);
-        if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, nbuf);
+        if (s + STAGES - 1 < nsteps) issue(nbuf);
         const unsigned char *st = lds + buf * kStage;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -770,6 +787,8 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     a.steps_main = taps * Cin / 64;
     a.steps_total = a.steps_main + a.Cin2 / 64;
     a.w_row = taps * Cin + a.Cin2;
+    auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); };
+    a.magic_w = magic((uint32_t)W); a.magic_h = magic((uint32_t)H); a.magic_chunks = magic((uint32_t)(Cin / 64));
     a.stamps = g_stamps;
     a.in_launch_reduce = p.in_launch;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
