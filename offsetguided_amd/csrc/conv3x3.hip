@@ -143,7 +143,7 @@ conv3x3_kernel(ConvArgs a)
     constexpr int MT = BM / 32, NT = BN / 32;       // 16-wide sub-tiles per wave (2 x 2 waves)
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: an SGPR
     CONV_STAMP(0);
     const int m_tile = blockIdx.x / a.n_tiles, n_tile = blockIdx.x % a.n_tiles, split = blockIdx.y;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -229,18 +229,20 @@ conv3x3_kernel(ConvArgs a)
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int px_off[MT], w_off[NT], px_sw[MT], w_sw[NT];
+    // fragment byte offsets inside a stage (swizzle applied), one per (sub-tile, k half): the loop below is unrolled
+    // over the ring so that the stage base folds into the ds_read immediate
+    uint32_t pfa[MT][2], wfa[NT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int r = wm * (BM / 2) + m * 16 + frow;
-        px_off[m] = r * kRowB;
-        px_sw[m] = (r >> 1) & 7;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) pfa[m][kh] = r * kRowB + (((fk + 4 * kh) ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int r = wn * (BN / 2) + n * 16 + frow;
-        w_off[n] = BM * kRowB + r * kRowB;
-        w_sw[n] = (r >> 1) & 7;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) wfa[n][kh] = BM * kRowB + r * kRowB + (((fk + 4 * kh) ^ ((r >> 1) & 7)) << 4);
     }
 
     // ---- prologue: STAGES-1 steps in flight (the host guarantees nsteps >= STAGES-1)
@@ -248,32 +250,32 @@ conv3x3_kernel(ConvArgs a)
     for (int j = 0; j < STAGES - 1; ++j) issue(j);
     CONV_STAMP(1);
 
-    int buf = 0, nbuf = STAGES - 1;
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + STAGES - 2 < nsteps) wait_vm_lgkm0<(STAGES - 2) * G>();
-        else wait_vm_lgkm0<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s == 0) CONV_STAMP(2);
-        if (s + STAGES - 1 < nsteps) issue(nbuf);
-        const unsigned char *st = lds + buf * kStage;
+    for (int s0 = 0; s0 < nsteps; s0 += STAGES) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 pf[MT], wf[NT];
+        for (int b = 0; b < STAGES; ++b) {               // b = ring slot of step s0 + b (compile time)
+            const int s = s0 + b;
+            if (s >= nsteps) break;
+            if (s + STAGES - 2 < nsteps) wait_vm_lgkm0<(STAGES - 2) * G>();
+            else wait_vm_lgkm0<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s == 0) CONV_STAMP(2);
+            if (s + STAGES - 1 < nsteps) issue((b + STAGES - 1) % STAGES);
+            const unsigned char *st = lds + b * kStage;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                pf[m] = *reinterpret_cast<const bf16x8 *>(st + px_off[m] + (((fk + 4 * kh) ^ px_sw[m]) << 4));
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 pf[MT], wf[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                wf[n] = *reinterpret_cast<const bf16x8 *>(st + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+                for (int m = 0; m < MT; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(st + pfa[m][kh]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+                for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const bf16x8 *>(st + wfa[n][kh]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+            }
         }
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
 
     CONV_STAMP(3);
