@@ -104,7 +104,61 @@ __device__ __forceinline__ void wait_vm_lgkm0()
 // the per-piece set-up and the per-step tap arithmetic of the split-K kernel are latency, not throughput.
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }
 
-// Epilogue of one BM x BN tile: lane holds couts co..co+3 of pixel pm in acc[n][m].
+// Epilogue of one BM x BN tile: lane holds couts co..co+3 of pixel pm in acc[n][m].  Two phases so that the bias and
+// residual loads of ALL sub-tiles are in flight together (and, after a split-K hand-off, together with the slab
+// gather): written as one loop, every load waited for the previous sub-tile's store (`out` may alias `skip` as far as
+// the compiler knows) -- eight dependent round trips, 4 of the 13 us of a 5x5 layer.
+template <int BM, int BN>
+struct EpiloguePre {
+    f32x4 bias[BN / 32];
+    u16x4 skip[BM / 32][BN / 32];
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_load(EpiloguePre<BM, BN> &pre, const ConvArgs &a, int m0, int n0, int wave, int lane)
+{
+    constexpr int MT = BM / 32, NT = BN / 32;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        pre.bias[n] = *reinterpret_cast<const f32x4 *>(a.bias + n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pm = m0 + wm * (BM / 2) + m * 16 + (lane & 15);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
+            pre.skip[m][n] = (u16x4){0, 0, 0, 0};
+            if (a.skip && pm < a.M) pre.skip[m][n] = *reinterpret_cast<const u16x4 *>(a.skip + (size_t)pm * a.Cout + co);
+        }
+    }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_finish(const f32x4 (&acc)[BN / 32][BM / 32], const EpiloguePre<BM, BN> &pre,
+                                                const ConvArgs &a, int m0, int n0, int wave, int lane)
+{
+    constexpr int MT = BM / 32, NT = BN / 32;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pm = m0 + wm * (BM / 2) + m * 16 + (lane & 15);
+        if (pm >= a.M) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[n][m] + pre.bias[n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(pre.skip[m][n][j]);   // zeros without a residual operand
+            u16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(a.relu ? fmaxf(v[j], 0.f) : v[j]);
+            *reinterpret_cast<u16x4 *>(a.out + (size_t)pm * a.Cout + co) = o;
+        }
+    }
+}
+
+// One-pass form (128-wide tiles: the prefetched operands of 16 sub-tiles would not fit the register budget).
 template <int BM, int BN>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BN / 32][BM / 32], const ConvArgs &a, int m0, int n0,
                                                int wave, int lane)
@@ -279,6 +333,8 @@ conv3x3_kernel(ConvArgs a)
     }
 
     CONV_STAMP(3);
+    constexpr bool kPrefetchEpi = MT * NT <= 4;
+    EpiloguePre<BM, BN> pre;
     // ---- split-K meeting point: every split writes its fp32 tile as a lane-linear slab (1 KiB per wave store),
     // the split that arrives last adds the others to its registers and runs the epilogue.  Hand-off as
     // cdna_hip_programming.md "in-launch split-K reduction", sc1 form: write-through (sc1) slab stores ->
@@ -298,14 +354,20 @@ conv3x3_kernel(ConvArgs a)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const int tile = blockIdx.x;
         constexpr uint32_t kSlabBytes = NT * MT * 256 * 16;
+        // descriptor and scalar offsets pinned to SGPRs (readfirstlane): left to the compiler they sat in VGPRs and every
+        // buffer access was wrapped in a waterfall loop
+        uint64_t slab_base = reinterpret_cast<uint64_t>(a.partial) + (uint64_t)tile * a.ksplit * kSlabBytes;
+        slab_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(slab_base >> 32)) << 32) |
+                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slab_base);
         const __amdgpu_buffer_rsrc_t tile_slabs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<char *>(a.partial) + (size_t)tile * a.ksplit * kSlabBytes, 0, (int)(a.ksplit * kSlabBytes), 0x00020000);
+            reinterpret_cast<char *>(slab_base), 0, __builtin_amdgcn_readfirstlane((int)(a.ksplit * kSlabBytes)), 0x00020000);
+        const uint32_t own_off = __builtin_amdgcn_readfirstlane(split * kSlabBytes);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), tile_slabs,
-                                                       (n * MT + m) * 4096 + tid * 16, split * kSlabBytes, 16);
+                                                       (n * MT + m) * 4096 + tid * 16, own_off, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int *flag = reinterpret_cast<int *>(lds);
@@ -318,6 +380,7 @@ conv3x3_kernel(ConvArgs a)
         __syncthreads();
         CONV_STAMP(4);
         if (!*flag) return;
+        if constexpr (kPrefetchEpi) epilogue_load<BM, BN>(pre, a, m0, n0, wave, lane);   // in flight with the gather
         // all loads of a batch are issued before the first add (one memory round trip per batch, not per slab);
         // the own slab and slots past ksplit are read out of range, which a buffer load returns as 0
         // (64-wide tiles: 8 slabs = every plan's K split in ONE round trip; two dependent batches cost 2 us per layer)
@@ -330,7 +393,8 @@ conv3x3_kernel(ConvArgs a)
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 const int sp = sp0 + b;
-                const uint32_t soff = (sp < a.ksplit && sp != split) ? sp * kSlabBytes : a.ksplit * kSlabBytes;
+                const uint32_t soff = __builtin_amdgcn_readfirstlane(
+                    (sp < a.ksplit && sp != split) ? sp * kSlabBytes : a.ksplit * kSlabBytes);
 #pragma unroll
                 for (int i = 0; i < NT * MT; ++i)
                     part[b][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tile_slabs, i * 4096 + tid * 16, soff, 16));
@@ -344,7 +408,12 @@ conv3x3_kernel(ConvArgs a)
         }
     }
 
-    epilogue_store<BM, BN>(acc, a, m0, n0, wave, lane);
+    if constexpr (kPrefetchEpi) {
+        if (a.ksplit <= 1) epilogue_load<BM, BN>(pre, a, m0, n0, wave, lane);
+        epilogue_finish<BM, BN>(acc, pre, a, m0, n0, wave, lane);
+    } else {
+        epilogue_store<BM, BN>(acc, a, m0, n0, wave, lane);
+    }
     CONV_STAMP(5);
 }
 
