@@ -698,6 +698,14 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps
             const int sps = (steps + ks - 1) / ks, last = steps - (ks - 1) * sps;
             if (sps >= 4 && last >= p.stages - 1 && last >= 1) best = ks;
         }
+    if (M >= 2048 && max_ks > 1 && !e) {   // 20x20 at bs8 (tuning knob: OG_CONV_MID_PLAN="ksplit,stages")
+        int mk = 3, ms = 4;
+        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d", &mk, &ms);
+        if (mk >= 1 && mk <= 3 && (ms == 2 || ms == 3 || ms == 4) && (steps + mk - 1) / mk >= 4) {
+            const int sps = (steps + mk - 1) / mk, last = steps - (mk - 1) * sps;
+            if (last >= ms - 1 && (steps % mk == 0 || extra_steps)) { best = mk; p.stages = ms; }
+        }
+    }
     if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
     if (steps < p.stages - 1) return false;
     p.ksplit = best;
