@@ -158,26 +158,35 @@ __device__ __forceinline__ void epilogue_finish(const f32x4 (&acc)[BN / 32][BM /
     }
 }
 
-// One-pass form (128-wide tiles: the prefetched operands of 16 sub-tiles would not fit the register budget).
+// Row-batched form (128-wide tiles: the prefetched operands of all 16 sub-tiles would not fit the register budget):
+// the bias once, then per 16-pixel row block all its residual loads together -- MT dependent round trips instead of 2*MT*NT.
 template <int BM, int BN>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BN / 32][BM / 32], const ConvArgs &a, int m0, int n0,
                                                int wave, int lane)
 {
     constexpr int MT = BM / 32, NT = BN / 32;
     const int wm = wave >> 1, wn = wave & 1;
+    f32x4 bias[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        bias[n] = *reinterpret_cast<const f32x4 *>(a.bias + n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int pm = m0 + wm * (BM / 2) + m * 16 + (lane & 15);
         if (pm >= a.M) continue;
+        u16x4 sk[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int co = n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
-            f32x4 v = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + co);
-            if (a.skip) {
-                const u16x4 sk = *reinterpret_cast<const u16x4 *>(a.skip + (size_t)pm * a.Cout + co);
+            sk[n] = (u16x4){0, 0, 0, 0};
+            if (a.skip) sk[n] = *reinterpret_cast<const u16x4 *>(a.skip + (size_t)pm * a.Cout + co);
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += bf2f(sk[j]);
-            }
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[n][m] + bias[n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(sk[n][j]);
             u16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f2bf(a.relu ? fmaxf(v[j], 0.f) : v[j]);
@@ -698,12 +707,19 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps
             const int sps = (steps + ks - 1) / ks, last = steps - (ks - 1) * sps;
             if (sps >= 4 && last >= p.stages - 1 && last >= 1) best = ks;
         }
-    if (M >= 2048 && max_ks > 1 && !e) {   // 20x20 at bs8 (tuning knob: OG_CONV_MID_PLAN="ksplit,stages")
-        int mk = 3, ms = 4;
-        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d", &mk, &ms);
-        if (mk >= 1 && mk <= 3 && (ms == 2 || ms == 3 || ms == 4) && (steps + mk - 1) / mk >= 4) {
+    if (M >= 2048 && max_ks > 1 && !e) {   // 20x20 at bs8 (tuning knob: OG_CONV_MID_PLAN="bm,ksplit,stages")
+        int mb = 64, mk = 3, ms = 4;
+        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d,%d", &mb, &mk, &ms);
+        const bool bm_ok = mb == 64 || (mb == 128 && Cout % 128 == 0);
+        if (bm_ok && mk >= 1 && mk <= 3 && (ms == 3 || ms == 4 || (ms == 2 && mb == 64)) && (steps + mk - 1) / mk >= 4) {
             const int sps = (steps + mk - 1) / mk, last = steps - (mk - 1) * sps;
-            if (last >= ms - 1 && (steps % mk == 0 || extra_steps)) { best = mk; p.stages = ms; }
+            if (last >= ms - 1 && (steps % mk == 0 || extra_steps)) {
+                best = mk;
+                p.stages = ms;
+                p.bm = p.bn = mb;
+                p.m_tiles = (int)((M + mb - 1) / mb);
+                p.n_tiles = Cout / mb;
+            }
         }
     }
     if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
