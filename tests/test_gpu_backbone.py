@@ -36,6 +36,18 @@ def test_bias_act_matches_torch(dev, relu, with_skip):
     assert torch.equal(y, ref)
 
 
+def test_stage_timer_uses_fence_free_events(dev):
+    """_lib.stage_timer / TimingEvent (hipEventDisableSystemFence events on the launch stream) give sane durations."""
+    x = torch.zeros(1 << 24, device=dev)
+    _lib.profile_start()
+    for _ in range(3):
+        with _lib.stage_timer('fill', dev):
+            x.add_(1.0)
+    out = _lib.profile_stop()
+    assert len(out['fill']) == 3 and all(1.0 < t < 5e4 for t in out['fill']), out   # microseconds
+    assert float(x[0]) == 3.0
+
+
 def test_upsample2_add_matches_torch(dev):
     lib = _lib.load()
     up, low = _nhwc(2, 384, 10, 20, dev=dev), _nhwc(2, 384, 5, 10, dev=dev)
