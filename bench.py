@@ -94,9 +94,11 @@ def main():
     from offsetguided_amd import sharding
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
     rank, local_rank, world = sharding.env_rank()
-    dev = torch.device('cuda', local_rank)
+    # OG_BENCH_SHARE_DEVICE=1 (test aid for 1-GPU boxes): all ranks on device 0, control plane over gloo
+    share = os.environ.get('OG_BENCH_SHARE_DEVICE') == '1'
+    dev = torch.device('cuda', 0 if share else local_rank)
     torch.cuda.set_device(dev)
-    sharding.init(backend='nccl', device=dev)   # one process per GPU; RCCL only for barrier + timing MAX
+    sharding.init(backend='gloo' if share else 'nccl', device=dev)   # one process per GPU; RCCL only for barrier + timing MAX
 
     from offsetguided_amd import _lib, decoder, models, synth
     from offsetguided_amd.config import coco_data as cd
@@ -300,7 +302,7 @@ def main():
         print(json.dumps(line))
     import torch.distributed as dist
     if dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        sharding.barrier(dev)
         dist.destroy_process_group()
 
 

@@ -34,9 +34,13 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _on_device(device):
+    return device is not None and device.type == 'cuda' and dist.get_backend() == 'nccl'
+
+
 def barrier(device=None):
     if dist.is_initialized():
-        if device is not None and device.type == 'cuda':
+        if _on_device(device):
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
@@ -48,7 +52,7 @@ def max_over_ranks(value, device=None):
     """MAX of a python float over all ranks (the slowest rank defines the job time)."""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
+    t = torch.tensor([value], dtype=torch.float64, device=device if _on_device(device) else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
