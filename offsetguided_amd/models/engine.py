@@ -58,6 +58,7 @@ CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
 # ... and layers with at least this many pixels run on its halo-tiled variant where a tile shape exists: H, W multiples
 # of 16 (the 160x160 / 80x80 levels) or W == 40 (the 40x40 level).
 CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
+CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
@@ -104,7 +105,7 @@ class _Conv:
             pixels = n * ((h - 1) // st + 1) * ((w - 1) // st + 1)
             # stride 2: the split-K kernel wins where M is small (40x40 -> 20x20 and below at bs8: 30 / 15 / 12 us against
             # MIOpen + epilogue 48 / 30 / 26); the large stride-2 layers stay on MIOpen (CK is 1.2-1.6x faster there)
-            if pixels <= CONV3X3_MAX_PIXELS or (st == 1 and (
+            if pixels <= (CONV_S2_MAX_PIXELS if st == 2 else CONV3X3_MAX_PIXELS) or (st == 1 and (
                     pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
                     and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
                 return self._hip(x, skip)
