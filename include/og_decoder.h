@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 1
+#define OG_ABI_VERSION 2
 
 #define OG_OK 0
 #define OG_EINVAL (-1)    /* bad argument (shape, k, alignment, null pointer)        */
@@ -123,6 +123,29 @@ int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const fl
                               int vector_nd, const float *scales, int scales_mode, const float *jitter, int jitter_mode,
                               int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
                               float thre_hmp, float min_len, float resize_factor, float *limbs, void *stream);
+
+/* ---- a8+a9+a10 in ONE call: LimbsCollect.generate_limbs  decoder/collect.py:62-236 on (N,C,H,W) hi-res heatmaps ----
+ * = og_nms_topk_f32 (joint_dets, decoder/heatmap.py:52-59) followed by og_collect_limbs_full_f32, same arguments and
+ * bit-identical limbs.  topk_scores / topk_inds: optional (N,C,k) outputs of the joint_dets stage (both or neither).
+ * flags 0: three launches (band top-k, merge, pairing) queued back to back -- the measured-fastest form on MI355X.
+ * flags OG_LIMBS_SINGLE_LAUNCH: one persistent kernel -- one workgroup per CU streams a feedback-balanced share of the
+ *   planes' rows (one HBM read of the heatmaps), the last workgroup to finish an image merges its candidate lists and
+ *   writes the limb rows.  Shapes it does not take (W % 4 != 0, k > 64, planes much smaller than a workgroup's share of
+ *   rows) silently run as the three launches.  Measured slower than flags 0 at bs8 640x640, kept
+ *   as the basis of the next step.
+ * workspace: og_generate_limbs_workspace_bytes(N, C, H, W, k), 16-byte aligned, ZERO-FILLED ONCE by the caller
+ * (hipMemset) before its first use; every call leaves it ready for the next one (any shape, any flags).  Its first
+ * 64 KiB hold the only state that outlives a call (tickets, all zero between calls, and the row partition the
+ * persistent kernel's feedback step maintains).  One call at a time per workspace. */
+#define OG_LIMBS_SINGLE_LAUNCH 1
+int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
+                          const float *scales, int scales_mode, const float *jitter, int jitter_mode,
+                          int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                          float thre_hmp, float min_len, float resize_factor, float *topk_scores,
+                          int64_t *topk_inds, float *limbs, int flags, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+size_t og_generate_limbs_workspace_bytes(int N, int C, int H, int W, int k);
 
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,

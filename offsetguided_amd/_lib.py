@@ -15,7 +15,8 @@ if os.environ.get("OG_DECODER_LIB"):  # alternative build of the same ABI (kerne
     LIB_PATH = os.environ["OG_DECODER_LIB"]
 
 OG_OK, OG_EINVAL, OG_ENOSPC, OG_EHIP, OG_EUNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 1
+OG_LIMBS_SINGLE_LAUNCH = 1   # og_generate_limbs_f32 flags
+ABI_VERSION = 2
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 
@@ -35,6 +36,9 @@ SIGNATURES = {
     "og_collect_limbs_nd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_collect_limbs_ex_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
     "og_collect_limbs_full_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),
+    "og_generate_limbs_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp,
+                                   _i, _vp, _sz, _vp]),
+    "og_generate_limbs_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

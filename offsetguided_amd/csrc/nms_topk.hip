@@ -41,6 +41,11 @@
 #include <math.h>
 
 #include "bicubic.h"
+#ifdef OG_K1_STAMPS   // tuning harness: time points inside the limb pairing (value-dependent, so they cannot be hoisted)
+__device__ long long g_k1_stamps[1024 * 16];
+#define OG_COLLECT_STAMP(i, dep) do { if (threadIdx.x == 0 && g_k1_stamps[blockIdx.x * 16 + (i)] == 0 && (dep) == (dep)) g_k1_stamps[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#endif
+#include "collect_body.h"
 #include "og_common.h"
 
 namespace {
@@ -120,18 +125,34 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
         }
         return r;
     };
-    Px<VEC> hm_a = hmax3<VEC>(load_row(g.r0 - 1));
+    // The loads must be ISSUED in the order the rows are consumed: vmcnt counts in-order returns, so a prologue that the
+    // scheduler shuffles (the loads are independent) makes the first wait of every iteration a full drain -- vmcnt(0)
+    // at the loop head instead of vmcnt(PF-1), seen in the ISA of the PF = 8 build.  sched_barrier pins the order.
+    const Px<VEC> top = load_row(g.r0 - 1);
+    __builtin_amdgcn_sched_barrier(0);
     Px<VEC> v_b = load_row(g.r0);
-    Px<VEC> hm_b = hmax3<VEC>(v_b);
+    __builtin_amdgcn_sched_barrier(0);
     Px<VEC> q[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) q[u] = load_row(g.r0 + 1 + u);
+    for (int u = 0; u < PF; ++u) {
+        q[u] = load_row(g.r0 + 1 + u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    Px<VEC> hm_a = hmax3<VEC>(top);
+    Px<VEC> hm_b = hmax3<VEC>(v_b);
     for (int r = g.r0; r < g.r1; r += PF) {
         iter_begin(r);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const Px<VEC> v_c = q[u];
+            // a REAL copy out of the queue slot before it is reloaded: left to the compiler, the row lives on in the slot's
+            // registers as v_b, the reload gets other registers and the loop head copies the youngest load back
+            // (= waits for it: a drain per iteration)
+            Px<VEC> v_c;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(v_c.c[j]) : "v"(q[u].c[j]));
+            __builtin_amdgcn_sched_barrier(0);
             q[u] = load_row(r + u + 1 + PF);
+            __builtin_amdgcn_sched_barrier(0);
             const Px<VEC> hm_c = hmax3<VEC>(v_c);  // all lanes take part in the DPP shifts
             if (r + u < g.r1) emit(r + u, v_b, hm_a, hm_b, hm_c);  // centre row + horizontal maxima of rows r-1, r, r+1
             hm_a = hm_b;
@@ -705,6 +726,8 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     return OG_OK;
 }
 
+#include "k1_single.inc"
+
 }  // namespace
 
 OG_API size_t og_topk_workspace_bytes(long planes, int H, int W, int k)
@@ -759,3 +782,100 @@ OG_API int og_hmp_nms_f32(const float *heat, long planes, int H, int W, float *o
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
+
+// ---- a8+a9+a10 in one launch: LimbsCollect.generate_limbs  decoder/collect.py:62-236 ----
+namespace {
+
+#ifndef OG_K1_SINGLE_PF
+#define OG_K1_SINGLE_PF 8
+#endif
+constexpr int kSinglePF = OG_K1_SINGLE_PF;   // rows in flight per streaming wave
+
+size_t two_step_bytes(int N, int C, int H, int W, int k, bool need_lists)
+{
+    const size_t topk = og_topk_workspace_bytes((long)N * C, H, W, k);
+    if (topk == 0) return 0;
+    return kP2TicketBytes + og_align_up(topk, 256) + (need_lists ? og_align_up((size_t)N * C * k * 12, 256) : 0);
+}
+
+}  // namespace
+
+OG_API size_t og_generate_limbs_workspace_bytes(int N, int C, int H, int W, int k)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return 0;
+    P2Plan p;
+    const size_t single = make_plan2((long)N * C, H, W, k, C, device_cu_count(), &p) ? p.bytes : 0;
+    const size_t two = two_step_bytes(N, C, H, W, k, true);
+    return single > two ? single : two;
+}
+
+OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
+                                 const float *scales, int scales_mode, const float *jitter, int jitter_mode,
+                                 int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                                 float thre_hmp, float min_len, float resize_factor, float *topk_scores,
+                                 int64_t *topk_inds, float *limbs, int flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_generate_limbs_f32";
+    OG_REQUIRE(hmps_hr && offs && jf && jt && limbs && workspace, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE((topk_scores == nullptr) == (topk_inds == nullptr), OG_EINVAL, "%s: topk_scores and topk_inds go together", name);
+    OG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && L > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE((jitter_mode == 0 || jitter_mode == 1 || jitter_mode == 3) && (jitter_mode == 0) == (jitter == nullptr),
+               OG_EINVAL, "%s: jitter_mode 0 (no head), 1 (hi-res maps) or 3 (stride-4 maps), with a map exactly when not 0", name);
+    OG_REQUIRE(jitter_mode == 0 || (H == W && vector_nd == 2), OG_EUNSUPPORTED,
+               "%s: the jitter refinement indexes its maps [x][y] like the reference: square inputs, 2-component offsets", name);
+    OG_REQUIRE(scales_mode >= 0 && scales_mode <= 3 && (scales_mode == 0) == (scales == nullptr), OG_EINVAL,
+               "%s: scales_mode 0 (no scale head) .. 3, with a map exactly when it is not 0", name);
+    OG_REQUIRE(vector_nd == 2 || vector_nd == 4, OG_EUNSUPPORTED, "%s: vector_nd must be 2 or 4", name);
+    OG_REQUIRE(!(off_is_lowres || scales_mode >= 2 || jitter_mode == 3) || (H % 4 == 0 && W % 4 == 0), OG_EINVAL,
+               "%s: H,W must be multiples of 4", name);
+    OG_REQUIRE((long)H * W >= k, OG_EINVAL, "%s: selected index k out of range (k=%d > H*W=%ld)", name, k, (long)H * W);
+    OG_REQUIRE(2l * (H + W) - 4 >= k, OG_EINVAL, "%s: plane border smaller than k", name);
+    OG_REQUIRE((uintptr_t)workspace % 16 == 0, OG_EINVAL, "%s: workspace must be 16-byte aligned", name);
+    const og_collect::Args ca{offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode,
+                              jitter, jitter_mode, limbs};
+    P2Plan p;
+    const bool single = (flags & OG_LIMBS_SINGLE_LAUNCH) != 0 && (uintptr_t)hmps_hr % 16 == 0 &&
+                        make_plan2((long)N * C, H, W, k, C, device_cu_count(), &p);
+    if (!single) {  // shapes the persistent kernel does not take: the three-launch form
+        const bool own_lists = topk_scores == nullptr;
+        const size_t need = two_step_bytes(N, C, H, W, k, own_lists);
+        OG_REQUIRE(need != 0, OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d", name, W, k);
+        OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, need);
+        // the ticket area at the head of the workspace belongs to the persistent kernel: stay clear of it
+        char *ws2 = (char *)workspace + kP2TicketBytes;
+        const size_t topk = og_align_up(og_topk_workspace_bytes((long)N * C, H, W, k), 256);
+        float *sc = own_lists ? reinterpret_cast<float *>(ws2 + topk + (size_t)N * C * k * 8) : topk_scores;
+        int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
+        const int rc = og_nms_topk_f32(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, stream);
+        if (rc != OG_OK) return rc;
+        return og_collect_limbs_full_f32(sc, id, offs, off_is_lowres, vector_nd, scales, scales_mode, jitter, jitter_mode, N, C,
+                                         H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs, stream);
+    }
+    OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
+    P2Args a;
+    a.in = hmps_hr;
+    a.planes = N * C; a.H = H; a.W = W; a.k = k; a.kpad = p.kpad; a.cap = p.cap;
+    a.balance = p.balance; a.bal_magic = p.magic;
+    a.bal = reinterpret_cast<int *>((char *)workspace + p.bal_off);
+    a.teams = p.teams; a.panels = p.panels; a.panel_strips = p.panel_strips;
+    a.maxseg = p.maxseg; a.total_rows = p.total_rows;
+    a.tickets = reinterpret_cast<int *>((char *)workspace + p.tick_off);
+    a.wg_cnt = reinterpret_cast<int *>((char *)workspace + p.cnt_off);
+    a.wg_keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
+    a.group = C;
+    a.out_scores = topk_scores; a.out_inds = topk_inds;
+    a.collect = 1; a.nd = vector_nd;
+    a.ca = ca;
+    auto kern = generate_limbs_kernel<kSinglePF>;
+    if (p.lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: %s", name, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(p.G), dim3(64 * (p.teams * p.panels + 1)), p.lds, (hipStream_t)stream, a);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+#ifdef OG_K1_STAMPS
+OG_API void og_k1_debug_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1_stamps), sizeof(g_k1_stamps)); }
+#endif

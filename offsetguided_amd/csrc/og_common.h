@@ -84,3 +84,21 @@ __device__ __forceinline__ int og_count_greater(const uint64_t *keys, int n, uin
     for (; j < n; ++j) rank += (keys[j] > mine);
     return rank;
 }
+
+// Two ranks in one pass over the keys (the LDS reads are the cost).
+__device__ __forceinline__ void og_count_greater2(const uint64_t *keys, int n, uint64_t m1, uint64_t m2, int &r1, int &r2)
+{
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    int a1 = 0, a2 = 0, j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const v2u a = *reinterpret_cast<const v2u *>(keys + j);
+        const v2u b = *reinterpret_cast<const v2u *>(keys + j + 2);
+        const v2u c = *reinterpret_cast<const v2u *>(keys + j + 4);
+        const v2u d = *reinterpret_cast<const v2u *>(keys + j + 6);
+        a1 += (a.x > m1) + (a.y > m1) + (b.x > m1) + (b.y > m1) + (c.x > m1) + (c.y > m1) + (d.x > m1) + (d.y > m1);
+        a2 += (a.x > m2) + (a.y > m2) + (b.x > m2) + (b.y > m2) + (c.x > m2) + (c.y > m2) + (d.x > m2) + (d.y > m2);
+    }
+    for (; j < n; ++j) { a1 += (keys[j] > m1); a2 += (keys[j] > m2); }
+    r1 = a1;
+    r2 = a2;
+}

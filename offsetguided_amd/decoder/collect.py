@@ -1,11 +1,12 @@
 """Candidate limb collection (reference decoder/collect.py:21-273) on the HIP kernels K1+K2."""
 import logging
+import os
 
 import torch
 
 from .. import _lib
 from ..config.coco_data import COCO_KEYPOINTS, COCO_PERSON_SKELETON
-from .heatmap import _topk_raw, nms_topk_raw
+from .heatmap import _topk_raw
 
 LOG = logging.getLogger(__name__)
 
@@ -16,8 +17,12 @@ class LimbsCollect(object):
     Same constructor and `generate_limbs` contract as the reference class
     (decoder/collect.py:37-67).  The output rows are
     [x1, y1, v1, x2, y2, v2, ind1, ind2, len_delta, len_limb, limb_score, scale1, scale2].
-    Keypoint-scale and jitter-offset heads (off in every published configuration) are not
-    implemented on the device path and raise.
+    Keypoint-scale and jitter-offset heads (off in every published configuration) are supported:
+    K2 samples the stride-4 maps at the peaks with the arithmetic of F.interpolate(x4).
+
+    On hi-res heatmaps the whole of generate_limbs -- NMS, top-k and the pairing -- is ONE C call
+    (og_generate_limbs_f32): three launches queued back to back, or with `single_launch = True` (OG_K1_SINGLE=1) one
+    persistent kernel with identical results (measured slower on MI355X).
     """
 
     def __init__(self, hmp_s, off_s, *, topk=40, thre_hmp=0.08, min_len=3,
@@ -35,6 +40,7 @@ class LimbsCollect(object):
         self.include_scale = include_scale
         self.use_jitter_offset = use_jitter_offset
         self.jtypes_f, self.jtypes_t = self.pack_jtypes(skeleton)
+        self.single_launch = os.environ.get('OG_K1_SINGLE', '0') == '1'
         LOG.info('%d limbs, keypoint threshold %.4f, offset/heatmap unit ratio %.3f',
                  len(skeleton), thre_hmp, self.resize_factor)
 
@@ -100,18 +106,27 @@ class LimbsCollect(object):
             jitter = _lib.require_device(jitter, 'jomps')
             expect = (n, 2, h, w) if jitter_mode == 1 else (n, 2, h // 4, w // 4)
             assert tuple(jitter.shape) == expect, f'jitter maps {tuple(jitter.shape)}, expected {expect}'
+        if jitter is not None and h != w:   # the reference indexes the refinement maps [x][y] (collect.py:158-165)
+            raise NotImplementedError('the jitter-offset head needs square inputs (the reference indexes its maps [x][y])')
         limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
+        jf, jt = _lib.int_table(self.jtypes_f, dev), _lib.int_table(self.jtypes_t, dev)
         # one bracket round the whole generate_limbs boundary (K1 + K2): what bench.py prices as "K1"
         with _lib.stage_timer('k1f_fused_limbs' if hm_is_lowres else 'k1_generate_limbs', dev):
-            if hm_is_lowres:
-                scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)
-            else:
-                scores, inds = nms_topk_raw(hmps_hr, self.K)
+            if not hm_is_lowres:
+                ws = _lib.workspace(dev, lib.og_generate_limbs_workspace_bytes(n, c, h, w, self.K), 'limbs')   # zero-filled
+                _lib.check(lib.og_generate_limbs_f32(
+                    _lib.ptr(hmps_hr), _lib.ptr(offs), int(off_is_lowres), int(vector_nd),
+                    _lib.ptr(scales) if scales is not None else None, int(scales_mode),
+                    _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w, _lib.ptr(jf), _lib.ptr(jt),
+                    n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor), None, None,
+                    _lib.ptr(limbs), _lib.OG_LIMBS_SINGLE_LAUNCH if self.single_launch else 0, _lib.ptr(ws), ws.numel(),
+                    _lib.stream_ptr(dev)), lib)
+                return limbs
+            scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)   # K1-fused: upsample inside
             _lib.check(lib.og_collect_limbs_full_f32(
                 _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), int(vector_nd),
                 _lib.ptr(scales) if scales is not None else None, int(scales_mode),
-                _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w,
-                _lib.ptr(_lib.int_table(self.jtypes_f, dev)), _lib.ptr(_lib.int_table(self.jtypes_t, dev)),
+                _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w, _lib.ptr(jf), _lib.ptr(jt),
                 n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
                 _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)
         return limbs

@@ -1,0 +1,68 @@
+"""`bench.py --gpus N` must really create N ranks (one process per GPU, reference bring-up train_dist.py:151-152).
+
+CPU: the control plane (`--dry-run`: rendezvous, barriers, MAX-over-ranks, rank-0 JSON) with two gloo ranks.
+GPU: the whole two-rank bench flow -- over RCCL with one GPU per rank when the box has two, otherwise with both ranks
+on the box's one GPU and the control plane over gloo (OG_BENCH_SHARE_DEVICE=1, a test aid)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'OG_FORCE_DIST')}
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, f'expected ONE JSON line, got {len(lines)}:\n{stdout}'
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_that_many_ranks_dry_run():
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1
+    assert line['elapsed_s'] >= 0.02          # MAX over ranks: rank 1 sleeps 20 ms, rank 0 only 10
+
+
+def test_gpus_flag_must_match_the_launcher():
+    env = _clean_env(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry-run'], capture_output=True, text=True, timeout=120,
+                       env=env)
+    assert r.returncode != 0 and 'does not match WORLD_SIZE' in r.stderr
+
+
+def test_more_gpus_than_devices_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip('box has 64 devices')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '64'], capture_output=True, text=True, timeout=120,
+                       env=_clean_env(OG_BENCH_SHARE_DEVICE='0'))
+    assert r.returncode != 0 and 'HIP device(s) are visible' in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_on_the_gpu():
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = _clean_env() if two else _clean_env(OG_BENCH_SHARE_DEVICE='1')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                        '--no-extras'], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['control_plane'] == ('rccl' if two else 'gloo (ranks share one device: test aid)')
+    assert line['value'] > 0 and len(line['per_rank_images_per_sec']) == 2
+    # whole-job value = all ranks' images over the slowest rank's time
+    assert abs(line['value'] - 2 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3

@@ -116,3 +116,46 @@ def test_jitter_head_case(name):
                              min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
                              flip=flip, jitter_lr=jit)
     assert_poses_match(split_poses(g), poses)
+
+
+# ---- the reference-shaped Python restatement (bench.py's cpu_baseline, kind "restatement") ----
+@pytest.mark.parametrize("name", ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe640", "pipe640_flip"])
+def test_restatement_pipeline_case(name):
+    """oracle/restatement.py (torch-CPU ops + numpy grouping in a Pool, decoder/factory.py:52-96 shaped) against the
+    reference's own outputs: candidate lists, limbs and poses."""
+    import torch
+    from oracle import restatement as rs
+    g, hm, off = load_case(name)
+    flip = flip_tables() if int(g["flip"]) else None
+    dec = rs.Decoder(cd.COCO_PERSON_SKELETON, 2, k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"], min_len=FLAGS["min_len"],
+                     person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
+                     flip=(flip[0], flip[1], sorted(flip[2])) if flip else None)
+    try:
+        poses, limbs = dec.generate_poses(hm, off)
+    finally:
+        dec.close()
+    assert_limbs_match(g["limbs"], limbs, valid_only_thre=FLAGS["thre_hmp"])
+    assert_poses_match(split_poses(g), poses)
+    t_hm = torch.from_numpy(hm)
+    if flip:
+        t_hm = rs.flip_augment(t_hm, torch.from_numpy(off), flip[0], flip[1], sorted(flip[2]))[0]
+    s, i, _, _ = rs.topk_channel(rs.hmp_nms(rs.upsample(t_hm, torch.from_numpy(off)[:len(t_hm)])[0]), FLAGS["topk"])
+    pos = g["scores"] > 0                                        # ties among the zero fillers are torch's business
+    assert (s.numpy()[pos] == g["scores"][pos]).all() and (i.numpy()[pos] == g["inds"][pos]).all()
+
+
+def test_restatement_grouping_adversarial():
+    from oracle import restatement as rs
+    g = np.load(f"{GOLDEN}/grouping_adversarial.npz")
+    n = 0
+    for si, sk_name in enumerate(g["skeleton_names"]):
+        sk = getattr(cd, str(sk_name))
+        o = 0
+        for limbs, (K, M), cfg in zip(g[f"limbs_{si}"], g[f"kn_{si}"], g[f"cfg_{si}"]):
+            thre, dmax, use_scale, sort_dim = g["cfg_table"][cfg]
+            ref = g[f"poses_{si}"][o:o + M]
+            o += M
+            got = rs.group_skeletons(limbs[:, :K], sk, 17, thre, dmax, bool(use_scale), int(sort_dim))
+            assert got.shape == ref.shape and (got == ref).all(), (str(sk_name), n)
+            n += 1
+    assert n >= 200

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""K1 at the generate_limbs boundary (og_generate_limbs_f32 vs og_nms_topk_f32 + og_collect_limbs_full_f32) on the bs8
+640x640 synthetic batch: HIP events on the launch stream, several library builds in ONE process (same box, same clocks).
+
+  python tools/k1_bench.py [--libs a.so b.so ...] [--iters 40]
+
+For every library: (1) results of the single-launch form == three-launch form (bitwise), (2) HBM-cold timing (3 rotating
+hi-res batches, 669 MB > Infinity Cache), (3) timing directly behind K1a (the hi-res batch has just been written: the
+decode pipeline's situation), (4) the three-launch form in both situations."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from offsetguided_amd import _lib, synth  # noqa: E402
+from offsetguided_amd.config import coco_data as cd  # noqa: E402
+
+
+def load(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--libs', nargs='*', default=[_lib.LIB_PATH])
+    ap.add_argument('--iters', type=int, default=40)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--k', type=int, default=32)
+    ap.add_argument('--rotate', type=int, default=3, help='hi-res batches cycled through (1 = the decode pipeline: one buffer)')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    _lib.load()
+    st = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(st.cuda_stream)
+    n, c, k, L = a.batch, 17, a.k, 19
+    h = w = a.size
+    hm, off = synth.synth_batch(0, n, h, w)
+    lrs = [torch.from_numpy(hm).to(dev) * (1.0 - 0.01 * r) for r in range(a.rotate)]
+    t_off = torch.from_numpy(off).to(dev)
+    hrs = [torch.empty((n, c, h, w), device=dev) for _ in range(a.rotate)]
+    jf = _lib.int_table([x for x, _ in cd.COCO_PERSON_SKELETON], dev)
+    jt = _lib.int_table([y for _, y in cd.COCO_PERSON_SKELETON], dev)
+    nbytes = n * c * h * w * 4 + n * L * k * (8 + 52)
+
+    for path in a.libs:
+        lib = load(path)
+        tag = os.path.basename(path)
+
+        def k1a(i):
+            _lib.check(lib.og_upsample_bicubic4_f32(_lib.ptr(lrs[i % a.rotate]), n * c, h // 4, w // 4, _lib.ptr(hrs[i % a.rotate]), sp), lib)
+
+        for i in range(a.rotate):
+            k1a(i)
+        ws1 = torch.zeros(lib.og_generate_limbs_workspace_bytes(n, c, h, w, k), dtype=torch.uint8, device=dev)
+        ws3 = torch.zeros(lib.og_topk_workspace_bytes(n * c, h, w, k), dtype=torch.uint8, device=dev)
+        limbs1 = torch.empty((n, L, k, 13), device=dev)
+        limbs3 = torch.empty((n, L, k, 13), device=dev)
+        sc = torch.empty((n, c, k), device=dev)
+        ix = torch.empty((n, c, k), dtype=torch.int64, device=dev)
+
+        def single(i):
+            _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[i % a.rotate]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
+                                                 _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs1),
+                                                 1, _lib.ptr(ws1), ws1.numel(), sp), lib)
+
+        def three(i):
+            _lib.check(lib.og_nms_topk_f32(_lib.ptr(hrs[i % a.rotate]), n * c, h, w, k, _lib.ptr(sc), _lib.ptr(ix), _lib.ptr(ws3),
+                                           ws3.numel(), sp), lib)
+            _lib.check(lib.og_collect_limbs_full_f32(_lib.ptr(sc), _lib.ptr(ix), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h,
+                                                     w, _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(limbs3), sp), lib)
+
+        ok = True
+        for i in range(a.rotate):
+            single(i)
+            three(i)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(limbs1, limbs3)
+        tick = int(ws1[:61440].view(torch.int32).abs().sum())
+
+        def timed(fn, pre=None):
+            for i in range(4):
+                if pre:
+                    pre(i)
+                fn(i)
+            torch.cuda.synchronize()
+            evs = []
+            for i in range(a.iters):
+                if pre:
+                    pre(i)
+                s, e = _lib.TimingEvent(), _lib.TimingEvent()
+                s.record(st)
+                fn(i)
+                e.record(st)
+                evs.append((s, e))
+            torch.cuda.synchronize()
+            t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
+            return float(np.median(t)), float(t.min())
+
+        res = {'single cold': timed(single), 'three cold': timed(three),
+               'single after K1a': timed(single, k1a), 'three after K1a': timed(three, k1a)}
+        st = ws1[61440:65536].view(torch.int32).cpu().numpy()
+        rows = np.diff(st[16:16 + 257])
+        print(f'== {tag}: single == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
+        for name, (med, mn) in res.items():
+            print(f'   {name:18s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
+        sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    main()
