@@ -77,28 +77,33 @@ class GreedyGroup(object):
 
 
 def soft_nms(subset, suppressed_v=0):
-    """Keypoint-level suppression over finished poses (decoder/group.py:249-283; its only call there, :183, is commented
-    out).  Host-side like the reference: `subset` is the list / array of (n_keypoints, 6) poses already copied back.
-    Per keypoint type an occupancy grid: a keypoint that lands on an occupied cell gets the score `suppressed_v`,
-    otherwise it occupies the square of half-width max(10, scale) round itself.  Modifies `subset` in place."""
+    """Keypoint-level suppression over finished poses (decoder/group.py:249-289 there; dead code upstream: its only call,
+    :183, is commented out).  Host-side, on the poses already copied back; modifies `subset` in place and returns it.
+
+    Every keypoint type has its own occupancy plane.  Poses are visited in order: a keypoint whose (clipped, truncated)
+    pixel is already covered gets the score `suppressed_v`; otherwise it covers the square of half-width
+    max(10, keypoint scale) round itself (at least one pixel, clipped to the plane).  The planes are independent, so this
+    walks them one keypoint type at a time."""
     if not len(subset):
         return subset
-    occupied = np.zeros((len(subset[0]),
-                         int(max(np.max(ann[:, 1]) for ann in subset) + 1),
-                         int(max(np.max(ann[:, 0]) for ann in subset) + 1)), dtype=np.uint8)
-    for ann in subset:
-        joint_scales = np.maximum(10.0, ann[:, 3])
-        assert len(occupied) == len(ann)
-        for xyv, occ, width in zip(ann[:, :3], occupied, joint_scales):
-            if xyv[2] == -1:
+    height = int(max(float(pose[:, 1].max()) for pose in subset) + 1)
+    width = int(max(float(pose[:, 0].max()) for pose in subset) + 1)
+    n_types = len(subset[0])
+    for j in range(n_types):
+        covered = np.zeros((height, width), dtype=bool)
+        for pose in subset:
+            assert len(pose) == n_types
+            x, y, v = pose[j, 0], pose[j, 1], pose[j, 2]
+            if v == -1:
                 continue
-            x = np.clip(xyv[0], 0.0, occ.shape[1] - 1).astype(int)
-            y = np.clip(xyv[1], 0.0, occ.shape[0] - 1).astype(int)
-            if occ[y, x]:
-                xyv[2] = suppressed_v
-            else:  # scalar_square_add_single (:280-285)
-                minx, miny = max(0, int(xyv[0] - width)), max(0, int(xyv[1] - width))
-                maxx = max(minx + 1, min(occ.shape[1], int(xyv[0] + width) + 1))
-                maxy = max(miny + 1, min(occ.shape[0], int(xyv[1] + width) + 1))
-                occ[miny:maxy, minx:maxx] += 1
+            col = int(min(max(x, 0.0), width - 1))
+            row = int(min(max(y, 0.0), height - 1))
+            if covered[row, col]:
+                pose[j, 2] = suppressed_v
+                continue
+            half = max(10.0, pose[j, 3])
+            x0, y0 = max(0, int(x - half)), max(0, int(y - half))
+            x1 = max(x0 + 1, min(width, int(x + half) + 1))
+            y1 = max(y0 + 1, min(height, int(y + half) + 1))
+            covered[y0:y1, x0:x1] = True
     return subset

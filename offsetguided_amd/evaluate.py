@@ -123,19 +123,27 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
     processor = decoder.decoder_factory(args)
     if data_loader is None:
         data_loader = synthetic_loader(n_synthetic_batches, args.batch_size, args.long_edge, dev)
-    engine, batch_time, end, pending = None, AverageMeter(), time.time(), None
+    feeder = DeviceFeeder(dev)
+    engines = {}            # one engine (scratch + captured graph) per input shape; a ragged last batch is padded instead
+    batch_time, end, last_print, pending = AverageMeter(), time.time(), -1, None
+    full_batch = None
 
     def collect(handle):
         poses, metas = handle
-        for image_poses, image_meta in zip(poses.result(), metas):
+        for image_poses, image_meta in zip(poses.result(), metas):   # zip drops the padded images of a ragged batch
             poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids)
 
     for batch_idx, (images, _, metas) in enumerate(data_loader):
-        images = images.to(dev, non_blocking=True)
+        images = feeder(images)
+        full_batch = full_batch or images.shape[0]
+        if images.shape[0] < full_batch:   # last batch of the dataset: fill up to the engine's batch, results are dropped
+            images = torch.cat((images, images[-1:].expand(full_batch - images.shape[0], -1, -1, -1)))
         if args.flip_test:
             images = torch.cat((images, torch.flip(images, [-1])))
-        if engine is None or engine.shape != tuple(images.shape):
-            engine = models.InferenceEngine(model, *images.shape[:1], images.shape[2], images.shape[3], device=dev)
+        engine = engines.get(tuple(images.shape))
+        if engine is None:
+            engine = engines[tuple(images.shape)] = models.InferenceEngine(
+                model, images.shape[0], images.shape[2], images.shape[3], device=dev, feat_stage=args.feat_stage)
         outputs = engine(images)
         handle = (processor.submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
         if pending is not None:
@@ -143,13 +151,46 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
         pending = handle
         if batch_idx % args.print_freq == 0:
             torch.cuda.synchronize()
-            batch_time.update((time.time() - end) / args.print_freq)
-            end = time.time()
-            print('==================> [{0}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tSpeed {1:.3f} ({2:.3f})'.format(
-                batch_idx, args.batch_size / batch_time.val, args.batch_size / batch_time.avg, bt=batch_time))
+            now = time.time()
+            per_batch = (now - end) / (batch_idx - last_print)   # batches since the last print (1 at the first), not print_freq
+            end, last_print = now, batch_idx
+            if batch_idx > 0:                                    # the first batch builds the engine: not a speed sample
+                batch_time.update(per_batch)
+            print('==================> [{0}]\tTime {1:.3f} ({2:.3f})\tSpeed {3:.3f} ({4:.3f})'.format(
+                batch_idx, per_batch, batch_time.avg or per_batch, args.batch_size / per_batch,
+                args.batch_size / (batch_time.avg or per_batch)))
     if pending is not None:
         collect(pending)
     return result_keypoints, result_image_ids
+
+
+class DeviceFeeder:
+    """Host batch -> device through two pinned staging buffers (the data loader's tensors are pageable: a direct
+    `.to(device, non_blocking=True)` from them is a synchronous staged copy).  The copy of batch i+1 is queued on its own
+    stream while batch i computes; a batch that already lives on the device passes through."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.slots, self.turn = [None, None], 0
+
+    def __call__(self, images):
+        if images.is_cuda:
+            return images
+        slot = self.slots[self.turn]
+        if slot is None or slot[0].shape != images.shape or slot[0].dtype != images.dtype:
+            slot = self.slots[self.turn] = [torch.empty(images.shape, dtype=images.dtype).pin_memory(), None]
+        if slot[1] is not None:
+            slot[1].synchronize()                # the copy that last used this staging buffer has left the host
+        slot[0].copy_(images)
+        with torch.cuda.stream(self.stream):
+            out = slot[0].to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(self.stream)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        out.record_stream(torch.cuda.current_stream(self.device))
+        self.turn ^= 1
+        return out
 
 
 def validation(args, data_loader=None):

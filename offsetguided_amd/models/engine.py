@@ -1,18 +1,24 @@
 """MI355X inference engine for NetworkWrapper(Hourglass104 + hmp/omp heads).
 
-The dense convolutions stay on PyTorch-ROCm (MIOpen -> MFMA); what this file adds is the shape
-the hardware wants:
+What this file adds to the eager module is the shape the hardware wants:
   * every BatchNorm folded into the preceding convolution (160 BN layers disappear);
-  * bias + ReLU + residual add after each convolution, and nearest-x2-upsample + add at every
-    hourglass merge, run as ONE hand-written HIP pass each (csrc/epilogue.hip) instead of 2-3
-    PyTorch elementwise launches;
-  * bf16 activations/weights in channels-last (NHWC) layout, fp32 accumulation inside MIOpen;
-  * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only);
-  * the whole forward (~500 launches, tiny 5x5..20x20 tiles deep in the hourglass) is captured
-    once into a HIP graph and replayed: launch latency, not math, bounds the deep levels;
-  * head outputs leave as dense fp32 NCHW tensors, the layout the HIP decoder kernels stream.
+  * bf16 (or fp16, the reference's apex-O2 arithmetic) activations / weights in channels-last (NHWC) layout;
+  * the 3x3 stride-1 convolutions -- 92 % of the FLOPs -- on the hand-written MFMA kernels of csrc/conv3x3.hip
+    (og_conv3x3_bf16: halo-tiled direct convolution for the 160x160 / 80x80 / 40x40 levels, split-K implicit GEMM with
+    the reduction inside the launch for 20x20 / 10x10 / 5x5), bias + ReLU + residual add fused into their epilogues,
+    fp32 accumulation in the MFMA accumulators; the stride-2 / projection layers of the small levels on the same
+    split-K kernel (og_conv2d_bf16, og_conv2d_proj_bf16), the stem on csrc/stem.hip;
+  * what is left on MIOpen (large stride-2 3x3, 1x1 junctions: 0.7 ms of 7) gets its bias / ReLU / residual pass and the
+    nearest-x2-upsample + add of every hourglass merge as ONE hand-written HIP pass each (csrc/epilogue.hip);
+  * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only), all of them as one
+    1x1 convolution whose result leaves as dense fp32 NCHW tensors, the layout the HIP decoder kernels stream;
+  * the whole forward (~170 launches, the up1 branches of every level forked onto side streams) is captured once into
+    a HIP graph and replayed: launch latency, not math, bounds the deep levels.
 The result keeps the reference nesting [ (hmps[S], bg[S], jo[S]), (offs[S], spreads[S], scales[S]) ]
 (models/networks.py:189-194); stacks that are not decoded hold None.
+
+Building an engine does not touch the caller's module: the weights are folded from its state_dict, the module's
+train / eval flag and device stay as they are.
 """
 import os
 
@@ -23,14 +29,20 @@ from .. import _lib
 from .hourglass_104 import ConvBlock, HourglassLevel, Residual
 
 
+_build_device = None   # device the folded weights of the engine under construction go to
+
+
 def _fold(conv, bn):
-    """conv (+ optional BatchNorm in eval mode) -> (weight, bias) fp32."""
+    """conv (+ optional BatchNorm, folded with its running statistics whatever the module's train / eval flag) ->
+    (weight, bias) fp32 on the engine's device.  Reads the module, never modifies or moves it."""
     w = conv.weight.detach().float()
     b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
     if isinstance(bn, torch.nn.BatchNorm2d):
         scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
         w = w * scale[:, None, None, None]
         b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+    if _build_device is not None:
+        w, b = w.to(_build_device), b.to(_build_device)
     return w, b
 
 
@@ -224,7 +236,7 @@ class InferenceEngine:
     def __init__(self, model, batch, height, width, dtype=torch.bfloat16, device='cuda:0', feat_stage=-1,
                  use_graph=True):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
-        global _n_engines
+        global _n_engines, _build_device
         self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
         _n_engines += 1
         self.device = torch.device(device)
@@ -233,8 +245,9 @@ class InferenceEngine:
         net = model.basenet
         self.n_stacks = net.nstack
         self.stage = feat_stage % self.n_stacks
-        dev_model = model.to(self.device).eval()
-        net = dev_model.basenet
+        # the caller's module is only read: weights are folded from it onto the engine's device (no .to(), no .eval())
+        _build_device = self.device
+        dev_model = model
         assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
         # hand-written HIP epilogues (bias/ReLU/residual add, upsample+add) on the GPU bf16 path
         fused = self.fused = (self.device.type == 'cuda' and dtype == torch.bfloat16)
@@ -279,6 +292,7 @@ class InferenceEngine:
                 b = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
             self.heads_w = w.contiguous(memory_format=torch.channels_last)
             self.heads_b = b.contiguous()
+        _build_device = None
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -330,7 +344,9 @@ class InferenceEngine:
         return (hm, off) + extra
 
     def _capture(self):
-        # MIOpen "find" picks per-shape kernels during the warm-up passes (1.4x over the defaults here)
+        # MIOpen "find" picks per-shape kernels during the warm-up passes (1.4x over the defaults here); the process-wide
+        # flag is put back afterwards
+        benchmark_before = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = True
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -344,6 +360,7 @@ class InferenceEngine:
         trunk = torch.cuda.Stream(self.device, priority=-1) if int(os.environ.get('OG_ENGINE_TRUNK_PRIORITY', '0')) else None
         with torch.no_grad(), torch.cuda.graph(self._graph, stream=trunk):
             self._out = self._forward(self._static_in)
+        torch.backends.cudnn.benchmark = benchmark_before
 
     @torch.no_grad()
     def forward_raw(self, images):

@@ -36,6 +36,14 @@ def train_cli(argv=None):
     p.add_argument('--steps-per-epoch', default=20, type=int, help='synthetic-data epoch length')
     p.add_argument('--no-sync-bn', dest='sync_bn', action='store_false', default=True)
     p.add_argument('--print-freq', '-f', default=10, type=int)
+    p.add_argument('--bench', action='store_true', default=False,
+                   help='BASELINE configs[4] measurement: time --bench-steps training steps (after --bench-warmup) on synthetic '
+                        'annotations and print ONE JSON line (step ms, images/s over all ranks, gradient all-reduce bus GB/s); '
+                        'no checkpoint is written')
+    p.add_argument('--bench-steps', default=20, type=int)
+    p.add_argument('--bench-warmup', default=5, type=int)
+    p.add_argument('--grad-compress', default='bf16', choices=['none', 'bf16'],
+                   help='DDP gradient all-reduce payload: fp32 (750.9 MB) or bf16-compressed (375.5 MB)')
     g = p.add_argument_group('optimizer configuration')
     g.add_argument('--optimizer', type=str, default='adam', choices=['sgd', 'adam'])
     g.add_argument('--learning-rate', type=float, default=2.5e-4, help='learning rate for world size 1')
@@ -99,6 +107,68 @@ def train_step(model, criterion, optimizer, images, annos, lambdas, autocast_dty
     return loss.detach(), [float(l.detach()) if torch.is_tensor(l) else float(l) for l in multi_losses]
 
 
+def bench_steps(args, model, criterion, optimizer, pool, encoders, dev, rank, world):
+    """BASELINE configs[4]: step time of the DDP training step (fused HIP losses, device-side GT encoding, bf16 autocast)
+    and the gradient all-reduce's bus bandwidth.  The all-reduce overlaps backward inside the step, so its bandwidth is
+    measured on its own: the same payload (one flat buffer of the gradients' size, the bucketed hook's dtype) reduced
+    back to back over RCCL; bus GB/s = bytes x 2 (N - 1) / N / time (ring convention).  `exposed_comm_ms` = step time
+    minus the same step under no_sync()."""
+    import contextlib
+    import json
+    use_cuda = dev.type == 'cuda'
+    dist = torch.distributed
+
+    def run(n, first, sync_grads=True):
+        ctx = contextlib.nullcontext() if (sync_grads or world == 1) else model.no_sync()
+        with ctx:
+            for step in range(first, first + n):
+                images, annos = pool[step % len(pool)]
+                if encoders is not None:
+                    annos = encode_targets(encoders, *annos)
+                train_step(model, criterion, optimizer, images, annos, args.lambdas, torch.bfloat16 if use_cuda else None)
+
+    def timed(n, first, **kw):
+        sharding.barrier(dev if use_cuda else None)
+        t0 = time.perf_counter()
+        run(n, first, **kw)
+        sharding.barrier(dev if use_cuda else None)
+        return sharding.max_over_ranks(time.perf_counter() - t0, dev if use_cuda else None) / n
+
+    model.train()
+    run(max(args.bench_warmup, 1), 0)
+    step_s = timed(args.bench_steps, args.bench_warmup)
+    nosync_s = timed(max(args.bench_steps // 2, 1), 0, sync_grads=False) if world > 1 else step_s
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    payload_dtype = torch.bfloat16 if (args.grad_compress == 'bf16' and use_cuda) else torch.float32
+    nbytes = n_params * (2 if payload_dtype == torch.bfloat16 else 4)
+    comm_ms = bus = None
+    if world > 1:
+        flat = torch.zeros(n_params, dtype=payload_dtype, device=dev)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        sharding.barrier(dev if use_cuda else None)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(flat)
+        sharding.barrier(dev if use_cuda else None)
+        comm_s = sharding.max_over_ranks(time.perf_counter() - t0, dev if use_cuda else None) / reps
+        comm_ms, bus = round(comm_s * 1e3, 3), round(nbytes * 2 * (world - 1) / world / comm_s / 1e9, 1)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training images/sec (DDP step: forward + fused losses + backward + all-reduce + fused Adam)',
+            'value': round(world * args.batch_size / step_s, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.bench_steps, 'warmup': args.bench_warmup, 'ms_per_step': round(step_s * 1e3, 2),
+            'config': {'workload': f'train_dist DDP, {args.square_length}x{args.square_length} crops, bs{args.batch_size}/GPU, '
+                                   'bf16 autocast, focal-L2 hmp + L1 offset losses (BASELINE configs[4])',
+                       'sync_bn': bool(args.sync_bn and world > 1), 'grad_payload': str(payload_dtype).replace('torch.', '')},
+            'grad_allreduce': {'bytes': nbytes, 'ms': comm_ms, 'bus_GBps': bus,
+                               'exposed_comm_ms': round(max(step_s - nosync_s, 0.0) * 1e3, 2) if world > 1 else 0.0},
+            'data': 'synthetic annotations, GT encoded on the device'}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     args = train_cli(argv)
     rank, local_rank, world = sharding.env_rank()
@@ -114,15 +184,31 @@ def main(argv=None):
         model = model.to(memory_format=torch.channels_last)
     if world > 1 and args.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if use_cuda else None,
-                                                          bucket_cap_mb=25, gradient_as_bucket_view=True)
     params = [p for p in model.parameters() if p.requires_grad]
     if args.optimizer == 'adam':
         optimizer = torch.optim.Adam(params, lr=args.learning_rate * world, weight_decay=args.weight_decay, fused=use_cuda)
     else:
         optimizer = torch.optim.SGD(params, lr=args.learning_rate * world, momentum=args.momentum,
                                     weight_decay=args.weight_decay)
+    # continue a run (train_dist.py:219-233): weights, optimizer state and the epoch the LR schedule is at.  Before the DDP
+    # wrap, so every rank loads the same state and the first broadcast has nothing to fix.
+    start_epoch = 0
+    if args.resume:
+        if not args.checkpoint_whole:
+            raise ValueError('--resume needs --checkpoint-whole <file>')
+        model, optimizer, start_epoch, start_loss, _ = models.load_model(
+            model, args.checkpoint_whole, optimizer=optimizer, resume_optimizer=True, drop_layers=False, optimizer2cuda=use_cuda)
+        if rank == 0:
+            print(f'resumed {args.checkpoint_whole}: next epoch {start_epoch}, last train loss {start_loss:.4f}')
+    elif args.checkpoint_whole and os.path.isfile(args.checkpoint_whole):
+        # initialise from a checkpoint without its optimizer / epoch (fine-tuning, as evaluate.py:189-191 loads it)
+        model, *_ = models.load_model(model, args.checkpoint_whole, optimizer=None, resume_optimizer=False, drop_layers=False)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if use_cuda else None,
+                                                          bucket_cap_mb=25, gradient_as_bucket_view=True)
+        if args.grad_compress == 'bf16' and use_cuda:   # 375.5 MB instead of 750.9 MB over xGMI per step
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            model.register_comm_hook(None, default_hooks.bf16_compress_hook)
     os.makedirs(args.checkpoint_path, exist_ok=True)
     # a small rotating pool of synthetic batches per rank (generating targets on the host every step
     # would measure numpy, not the training step)
@@ -142,9 +228,12 @@ def main(argv=None):
             pool.append((imgs, (torch.from_numpy(joints).to(dev), torch.from_numpy(n_persons).to(dev))))
         else:
             pool.append((imgs, synthetic_targets(1000 * rank + i, args.batch_size, args.square_length, dev)))
-    for epoch in range(args.epochs):
+    if args.bench:
+        return bench_steps(args, model, criterion, optimizer, pool, encoders, dev, rank, world)
+    batch_time = AverageMeter()   # over the whole run: the first steps (MIOpen find, allocator warm-up) do not bias an epoch
+    for epoch in range(start_epoch, args.epochs):
         model.train()
-        batch_time, losses, end = AverageMeter(), AverageMeter(), time.time()
+        losses, end, last_print = AverageMeter(), time.time(), -1
         for step in range(args.steps_per_epoch):
             adjust_learning_rate(args.learning_rate, world, optimizer, epoch, step, args.steps_per_epoch, args.warmup)
             images, annos = pool[step % len(pool)]
@@ -158,12 +247,15 @@ def main(argv=None):
                     loss = loss / world
                 if use_cuda:
                     torch.cuda.synchronize()
-                batch_time.update((time.time() - end) / args.print_freq)
-                end = time.time()
+                now = time.time()
+                per_step = (now - end) / (step - last_print)   # steps since the last print (1 at step 0), not print_freq
+                end, last_print = now, step
+                if epoch > start_epoch or step > 0:            # the very first step is warm-up: not a speed sample
+                    batch_time.update(per_step)
                 losses.update(float(loss))
                 if rank == 0:
                     print(f'epoch {epoch} [{step}/{args.steps_per_epoch}] loss {losses.val:.4f} ({losses.avg:.4f}) '
-                          f'speed {world * args.batch_size / batch_time.val:.1f} img/s')
+                          f'speed {world * args.batch_size / per_step:.1f} img/s')
         if rank == 0:
             models.save_model(os.path.join(args.checkpoint_path, f'PoseNet_{epoch}_epoch.pth'), epoch, losses.avg, model,
                               optimizer)

@@ -207,11 +207,7 @@ def test_grouping_golden_adversarial(dev):
 
 @pytest.mark.parametrize("sk_name", ["COCO_PERSON_SKELETON", "DENSER_COCO_PERSON_SKELETON"])
 def test_grouping_fuzz_vs_oracle(dev, sk_name):
-    import sys
-    sys.path.insert(0, "tools")
     sk = getattr(cd, sk_name)
-    L = len(sk)
-    rng0 = synth.HashRng(4242)
     cases = []
     for i in range(96):
         rng = synth.HashRng(880000 + i)
@@ -224,7 +220,6 @@ def test_grouping_fuzz_vs_oracle(dev, sk_name):
         for lim, p in zip(batch, got):
             ref = oracle.greedy_group(lim, sk, 17, 0.04, 40.0)
             assert p.shape == ref.shape and (p == ref).all()
-    assert L == len(sk) and rng0 is not None
 
 
 def _adversarial(rng, K, skeleton, hw=4096):

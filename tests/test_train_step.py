@@ -115,3 +115,64 @@ def test_gpu_train_steps_with_device_encoder(tmp_path):
     assert bool(torch.isfinite(off).any()) and bool(torch.isinf(off).any()) and float(ps.min()) >= 1.0
     train_dist.main(['--no-pretrain', '--square-length', '256', '--batch-size', '2', '--epochs', '1', '--steps-per-epoch', '3',
                      '--print-freq', '1', '--checkpoint-path', str(tmp_path)])
+
+
+def test_resume_restores_epoch_weights_and_optimizer(tmp_path, monkeypatch, capsys):
+    """--resume continues from --checkpoint-whole (reference train_dist.py:219-233): weights and optimizer state are
+    loaded, training restarts at the NEXT epoch (so the LR schedule does too) and earlier checkpoints are left alone."""
+    from offsetguided_amd import models, train_dist
+    torch.manual_seed(0)
+    monkeypatch.setattr(models, 'model_factory', lambda args: (TinyNet(), _criterion()))
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    common = ['--no-pretrain', '--square-length', '64', '--batch-size', '2', '--steps-per-epoch', '2', '--print-freq', '1',
+              '--checkpoint-path', str(tmp_path), '--lambdas', '1', '0', '0', '100', '0.01']
+    train_dist.main(common + ['--epochs', '2'])
+    first = sorted(os.listdir(tmp_path))
+    assert first == ['PoseNet_0_epoch.pth', 'PoseNet_1_epoch.pth']
+    stamp = os.path.getmtime(tmp_path / 'PoseNet_0_epoch.pth')
+    ck = torch.load(tmp_path / 'PoseNet_1_epoch.pth', map_location='cpu')
+    assert ck['epoch'] == 1 and 'optimizer_state_dict' in ck
+    out0 = capsys.readouterr().out
+    assert 'epoch 0 [0/2]' in out0 and 'epoch 1 [1/2]' in out0
+
+    train_dist.main(common + ['--epochs', '4', '--resume', '--checkpoint-whole', str(tmp_path / 'PoseNet_1_epoch.pth')])
+    out1 = capsys.readouterr().out
+    assert 'next epoch 2' in out1 and 'epoch 2 [0/2]' in out1 and 'epoch 0 [' not in out1 and 'epoch 1 [' not in out1
+    assert sorted(os.listdir(tmp_path)) == first + ['PoseNet_2_epoch.pth', 'PoseNet_3_epoch.pth']
+    assert os.path.getmtime(tmp_path / 'PoseNet_0_epoch.pth') == stamp
+    ck3 = torch.load(tmp_path / 'PoseNet_3_epoch.pth', map_location='cpu')
+    steps = [int(v['step']) for v in ck3['optimizer_state_dict']['state'].values()]
+    assert steps and all(s == 8 for s in steps)                 # 4 epochs x 2 steps: Adam's counters were carried over
+
+    with pytest.raises(ValueError):
+        train_dist.main(common + ['--resume'])
+
+
+def test_bench_mode_prints_one_json_line_cpu(tmp_path, monkeypatch, capsys):
+    import json
+    from offsetguided_amd import models, train_dist
+    monkeypatch.setattr(models, 'model_factory', lambda args: (TinyNet(), _criterion()))
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    train_dist.main(['--no-pretrain', '--square-length', '64', '--batch-size', '2', '--checkpoint-path', str(tmp_path), '--bench',
+                     '--bench-steps', '3', '--bench-warmup', '1', '--lambdas', '1', '0', '0', '100', '0.01'])
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['grad_allreduce']['bus_GBps'] is None
+    assert os.listdir(tmp_path) == []                            # no checkpoint in bench mode
+
+
+@pytest.mark.gpu
+def test_gpu_train_bench_line():
+    """train_dist --bench on the GPU (BASELINE configs[4] hook, one rank): the full Hourglass-104 step at 256x256 bs2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    r = subprocess.run([sys.executable, '-m', 'offsetguided_amd.train_dist', '--no-pretrain', '--square-length', '256',
+                        '--batch-size', '2', '--bench', '--bench-steps', '3', '--bench-warmup', '2'],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['grad_allreduce']['bytes'] == 2 * 187_729_270 or d['grad_allreduce']['bytes'] > 3e8
