@@ -139,37 +139,28 @@ __device__ __forceinline__ void limb_rows(const Args &a, int n, int l, int lane,
             }
         }
         const float gx2 = ND == 4 ? xf + o4[ND - 2] * resize : 0.f, gy2 = ND == 4 ? yf + o4[ND - 1] * resize : 0.f;
-        // collect.py:171-177: first minimum of dist = sqrt(d2) over the to-candidates.  A correctly rounded sqrtf per pair
-        // is ~20 dependent instructions, K of them per lane; sqrtf is monotonic, so min dist = sqrtf(min d2), and the
-        // FIRST candidate whose dist equals it can only be one whose d2 lies within a few ulp of min d2 (sqrtf halves the
-        // relative spacing: sqrtf(x) == sqrtf(m) implies x <= m * (1 + 2^-22)) -- only those take the sqrtf.
-        auto dist2 = [&](float cxj, float cyj) -> float {
-            const float dx = gx - cxj, dy = gy - cyj;
-            if (ND == 2) return __builtin_fmaf(dy, dy, dx * dx);
-            const float dx2 = gx2 - cxj, dy2 = gy2 - cyj;
-            return ((dx * dx + dy * dy) + dx2 * dx2) + dy2 * dy2;
-        };
-        float m2 = INFINITY;
-#pragma unroll 2
-        for (int m0 = 0; m0 < Kp; m0 += 4) {  // pass 1: min d2, 4 candidates per pair of wide LDS reads
+        // collect.py:171-177: first minimum of the distance over the to-candidates, 4 per pair of wide LDS reads.  (A
+        // variant that compares squared distances and takes the sqrtf only for candidates within 2^-21 of the minimum is
+        // exact too, but its two dependent passes over the LDS list measured 2 us SLOWER per launch than this single
+        // pass: the loop is bound by LDS latency, the sqrtf hides under it.)
+        int best = 0;
+        float bd = INFINITY;
+        for (int m0 = 0; m0 < Kp; m0 += 4) {
             const float4 a4 = *reinterpret_cast<const float4 *>(txy + m0), b4 = *reinterpret_cast<const float4 *>(txy + m0 + 2);
-            m2 = fminf(fminf(m2, fminf(dist2(a4.x, a4.y), dist2(a4.z, a4.w))), fminf(dist2(b4.x, b4.y), dist2(b4.z, b4.w)));
-        }
-        const float bd = sqrtf(m2);
-        const float lim = m2 * 1.0000005f;   // 1 + 2^-21: a superset of the candidates at distance bd
-        int best = Kp;
-#pragma unroll 2
-        for (int m0 = 0; m0 < Kp; m0 += 4) {  // pass 2: the first candidate at that distance
-            const float4 a4 = *reinterpret_cast<const float4 *>(txy + m0), b4 = *reinterpret_cast<const float4 *>(txy + m0 + 2);
-            const float d0 = dist2(a4.x, a4.y), d1 = dist2(a4.z, a4.w), d2 = dist2(b4.x, b4.y), d3 = dist2(b4.z, b4.w);
-            if (fminf(fminf(d0, d1), fminf(d2, d3)) <= lim) {   // rare: only here the sqrtf is taken
-                const int c = (d0 <= lim && sqrtf(d0) == bd) ? 0 : (d1 <= lim && sqrtf(d1) == bd) ? 1 :
-                              (d2 <= lim && sqrtf(d2) == bd) ? 2 : (d3 <= lim && sqrtf(d3) == bd) ? 3 : Kp;
-                best = min(best, m0 + c);
+            const float cx[4] = {a4.x, a4.z, b4.x, b4.z}, cy[4] = {a4.y, a4.w, b4.y, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = gx - cx[j], dy = gy - cy[j];
+                float d;
+                if (ND == 2) {
+                    d = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+                } else {
+                    const float dx2 = gx2 - cx[j], dy2 = gy2 - cy[j];
+                    d = sqrtf(((dx * dx + dy * dy) + dx2 * dx2) + dy2 * dy2);
+                }
+                if (d < bd) { bd = d; best = m0 + j; }   // strict <: first minimum wins
             }
         }
-        best = best >= Kp ? -1 : best;
-        best = best < 0 ? 0 : best;   // (all distances infinite: torch.min returns index 0)
 #ifdef OG_COLLECT_STAMP
         OG_COLLECT_STAMP(13, bd);
 #endif

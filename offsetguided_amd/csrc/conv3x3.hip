@@ -61,6 +61,7 @@ struct ConvArgs {
     uint32_t magic_w, magic_h, magic_chunks;   // ceil(2^32 / d) for d = W, H, Cin/64 (0 when d == 1): q = umulhi(n, magic)
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
+    int store_policy;            // halo kernel's output stores: 0 plain, 1 sc1 (write-through), 2 nt (OG_CONV_STORE)
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
 };
 
@@ -646,7 +647,13 @@ conv3x3_halo_kernel(ConvArgs a)
     for (int i = 0; i < kGroups / 512; ++i) {
         const int g = tid + 512 * i, px = g / kPerPx, cg = g % kPerPx;
         const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + n0 + cg * 8;
-        *reinterpret_cast<u16x8 *>(a.out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
+        const u16x8 v = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
+        // Write-through keeps the Infinity Cache free of DIRTY activations: the convolutions are MFMA-bound, so pushing
+        // their output to HBM at once costs them nothing, while dirty lines left behind are evicted on the clock of
+        // whatever memory-bound kernel comes next (the decoder's K1a / K1 paid 10-15 us for the backbone's leftovers).
+        if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a.out + off), "v"(v) : "memory");
+        else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a.out + off), "v"(v) : "memory");
+        else *reinterpret_cast<u16x8 *>(a.out + off) = v;
     }
     CONV_STAMP(5);
 }
@@ -835,6 +842,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
         h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
         h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
+        { static const int policy = getenv("OG_CONV_STORE") ? atoi(getenv("OG_CONV_STORE")) : 0; h.store_policy = policy; }
         h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
         h.stamps = g_stamps;
         h.x_bytes = (int)(M * Cin * 2);

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--k', type=int, default=32)
+    ap.add_argument('--burst', type=int, default=0, help='dense bf16 GEMMs (about this many ms) queued before every timed call: the clock / power state the decoder sees behind the backbone')
     ap.add_argument('--rotate', type=int, default=3, help='hi-res batches cycled through (1 = the decode pipeline: one buffer)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -108,11 +109,29 @@ def main():
 
         res = {'single cold': timed(single), 'three cold': timed(three),
                'single after K1a': timed(single, k1a), 'three after K1a': timed(three, k1a)}
+        if a.burst:
+            ga = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+            gb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ga @ gb
+            e1.record()
+            torch.cuda.synchronize()
+            reps = max(1, int(a.burst / (e0.elapsed_time(e1) / 10)))
+
+            def burst_then_k1a(i):
+                for _ in range(reps):
+                    ga @ gb
+                k1a(i)
+            res[f'single after {a.burst} ms of GEMM + K1a'] = timed(single, burst_then_k1a)
+            res[f'three after {a.burst} ms of GEMM + K1a'] = timed(three, burst_then_k1a)
         st = ws1[61440:65536].view(torch.int32).cpu().numpy()
         rows = np.diff(st[16:16 + 257])
         print(f'== {tag}: single == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
         for name, (med, mn) in res.items():
-            print(f'   {name:18s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
+            print(f'   {name:36s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
         sys.stdout.flush()
 
 
