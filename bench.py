@@ -60,6 +60,8 @@ def parse():
     ap.add_argument('--flip', action='store_true', help='flip-test (BASELINE config 3): 2x images through the backbone')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16',
+                    help='engine arithmetic: bf16 (default) or f16 (the reference evaluates in fp16 through apex O2); same MFMA rate')
     ap.add_argument('--no-extras', action='store_true',
                     help='headline region only: skip the decoder-only / backbone-only / conv / HBM-cold / flip measurements')
     ap.add_argument('--dry-run', action='store_true',
@@ -175,7 +177,7 @@ def main():
         def __init__(self, flip, inflight=1):
             self.flip = flip
             self.nb = a.batch * (2 if flip else 1)
-            self.engines = [models.InferenceEngine(model, self.nb, a.size, a.size, dtype=torch.bfloat16, device=dev,
+            self.engines = [models.InferenceEngine(model, self.nb, a.size, a.size, dtype=torch.float16 if a.dtype == 'f16' else torch.bfloat16, device=dev,
                                                    use_graph=not a.no_graph) for _ in range(inflight)]
             self.procs = [decoder.decoder_factory(margs) for _ in range(inflight)]
             self.engine, self.proc = self.engines[0], self.procs[0]
@@ -341,9 +343,9 @@ def main():
             'metric': METRIC,
             'value': round(imgs / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'bs{a.batch} {a.size}x{a.size}' + (' + flip-test' if a.flip else '') +
-                                   ': Hourglass-104+heads (bf16, HIP graph) -> HIP decoder topk=32, 17 heatmaps, 19 limbs'
+                                   ': Hourglass-104+heads (%s, HIP graph) -> HIP decoder' % a.dtype + ' topk=32, 17 heatmaps, 19 limbs'
                                    ' (BASELINE configs[%d])' % (2 if a.flip else 1),
                        'per_gpu_batch': a.batch, 'parallelism': f'batch-sharded x{world}, no collectives',
                        'control_plane': 'gloo (ranks share one device: test aid)' if share else 'rccl',

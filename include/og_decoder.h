@@ -244,6 +244,24 @@ int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, con
 size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int Cin2);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
+/* ---- the same entry points for fp16 activations / weights (the reference evaluates in fp16 through apex O2,
+ * evaluate.py:92,198-201): v_mfma_f32_16x16x32_f16 instead of ..._bf16, fp32 accumulation, identical layouts, arguments,
+ * workspaces (og_conv*_workspace_bytes) and error behaviour; models.InferenceEngine(dtype=torch.float16). ---- */
+int og_bias_act_f16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream);
+int og_upsample2_add_f16(void *up, const void *low, long n, int H, int W, int channels, void *stream);
+int og_nchw_f32_to_nhwc_f16(const float *src, void *dst, long N, int C, int H, int W, void *stream);
+int og_nhwc_f16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
+                            float *dst, long N, int H, int W, void *stream);
+int og_stem7x7_f16(const float *images, const void *w_packed, const float *bias, void *out, int N, int H, int W, int relu,
+                   void *stream);
+int og_conv3x3_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
+                   int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv2d_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin, int Win,
+                  int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv2d_proj_f16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,
+                       int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2, int stride2, int relu,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 void og_conv3x3_debug_stamps(void *buf);
 
 /* ---- training losses, value + gradient in one pass ----

@@ -64,7 +64,18 @@ SIGNATURES = {
     "og_offset_l1_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp, _vp, _vp]),
 }
 
+# fp16 twins of the 16-bit-type specific entry points (csrc/lp_dtype.h): same signatures
+for _name in [n for n in SIGNATURES if n.endswith('_bf16')]:
+    SIGNATURES[_name[:-5] + '_f16'] = SIGNATURES[_name]
+SIGNATURES['og_nhwc_f16_to_nchw_f32'] = SIGNATURES['og_nhwc_bf16_to_nchw_f32']
+
 _lib = None
+
+
+def lp(lib, stem, dtype):
+    """Entry point of the 16-bit-type specific family for a torch dtype: lp(lib, 'og_conv2d', torch.float16) -> og_conv2d_f16."""
+    import torch as _t
+    return getattr(lib, stem + ('_f16' if dtype == _t.float16 else '_bf16'))
 
 
 class OgError(RuntimeError):

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libog_decoder.so")
 SOURCES = ["abi.cpp", "nms_topk.hip", "upsample.hip", "collect.hip", "group.hip", "flip.hip", "epilogue.hip", "losses.hip", "conv3x3.hip", "encoder.hip", "stem.hip"]
+# the 16-bit-type specific files are compiled a second time for fp16 (csrc/lp_dtype.h)
+F16_SOURCES = ["conv3x3.hip", "epilogue.hip", "stem.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: every FMA in the kernels is explicit (bit-exact parity with torch-CPU fp32);
 # correctly-rounded fp32 divide/sqrt is hipcc's default and must stay on (no -ffast-math).
@@ -42,12 +44,12 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     objs, procs = [], []
-    for src in SOURCES:
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), *FLAGS, *inc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    for src, extra, tag in [(s_, [], "") for s_ in SOURCES] + [(s_, ["-DOG_DT_F16=1"], "_f16") for s_ in F16_SOURCES]:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + tag + ".o")
+        cmd = [_hipcc(), *FLAGS, *extra, *inc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src + tag, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()

@@ -31,11 +31,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "lp_dtype.h"
 #include "og_common.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef lp8 bf16x8;   // 8 x 16-bit operands of one MFMA fragment (lp_dtype.h)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -71,13 +72,8 @@ struct ConvArgs {
             a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return f2lp(f); }   // (bf16, or fp16 in the -DOG_DT_F16 build)
+__device__ __forceinline__ float bf2f(unsigned short u) { return lp2f(u); }
 
 __device__ __forceinline__ void glds16(const void *g, unsigned char *l)
 {
@@ -337,7 +333,7 @@ conv3x3_kernel(ConvArgs a)
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], pf[m], acc[n][m], 0, 0, 0);
+                        acc[n][m] = OG_LP_MFMA(wf[n], pf[m], acc[n][m]);
             }
         }
     }
@@ -603,7 +599,7 @@ conv3x3_halo_kernel(ConvArgs a)
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][n], pf[kh][m], acc[n][m], 0, 0, 0);
+                        acc[n][m] = OG_LP_MFMA(wf[kh][n], pf[kh][m], acc[n][m]);
             __builtin_amdgcn_s_setprio(0);
             {   // weight DMA behind the MFMA queue of this step (2 % faster in the network than issuing it in the R
                 // phase; the halo piece stays there: moving both costs 12 %)
@@ -753,7 +749,7 @@ size_t ws_layout(const Plan &p, size_t *counters_off, size_t *slabs_off)
     return s_off + (p.ksplit > 1 ? tiles * p.ksplit * (size_t)p.bm * p.bn * sizeof(float) : 0);
 }
 
-unsigned long long *g_stamps = nullptr;
+static unsigned long long *g_stamps = nullptr;
 
 // Large levels go to the halo-tiled kernel: 1 = 16x16 tiles (H, W multiples of 16), 2 = 40x4 full-width tiles
 // (W == 40, H multiple of 4), 0 = not applicable.  OG_CONV_HALO=0 disables, =1 forces it wherever the shape allows.
@@ -769,6 +765,10 @@ int halo_kind(long M, int H, int W, int Cin, int Cout)
 
 // Debug aid (tools/conv_bench.py --stamps): device buffer of [workgroups][8] u64 that later launches fill with
 // s_memrealtime marks; pass NULL to switch off.  Not part of the product path.
+static inline int conv_out_dim(int in, int ksize, int stride) { return (in + 2 * (ksize / 2) - ksize) / stride + 1; }
+
+// entry points that do not depend on the 16-bit type exist once in the library: defined by the bf16 build only
+#ifndef OG_DT_F16
 OG_API void og_conv3x3_debug_stamps(void *buf) { g_stamps = (unsigned long long *)buf; }
 
 OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
@@ -778,7 +778,6 @@ OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
     return ws_layout(p, nullptr, nullptr);
 }
 
-static inline int conv_out_dim(int in, int ksize, int stride) { return (in + 2 * (ksize / 2) - ksize) / stride + 1; }
 
 // Exact requirement for one layer: the halo-tiled kernel of the large levels needs no scratch beyond the fixed
 // head of the layout (the split-K slabs of og_conv3x3_workspace_bytes would be hundreds of MB there).
@@ -808,6 +807,8 @@ OG_API size_t og_conv3x3_workspace_bytes_nhw(int N, int H, int W, int Cin, int C
 {
     return og_conv2d_workspace_bytes(N, H, W, Cin, Cout, 3, 1);
 }
+
+#endif
 
 struct Proj {  // optional second operand: out += conv1x1(x2, stride2), weights appended along K
     const void *x2 = nullptr;
@@ -924,28 +925,28 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     return OG_OK;
 }
 
-OG_API int og_conv3x3_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,
+OG_API int OG_LP_NAME(og_conv3x3)(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H,
                            int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return conv_run("og_conv3x3_bf16", x, w, bias, skip, out, N, H, W, Cin, Cout, 3, 1, relu, workspace, workspace_bytes,
+    return conv_run(OG_LP_STR("og_conv3x3"), x, w, bias, skip, out, N, H, W, Cin, Cout, 3, 1, relu, workspace, workspace_bytes,
                     stream);
 }
 
-OG_API int og_conv2d_bf16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin,
+OG_API int OG_LP_NAME(og_conv2d)(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin,
                           int Win, int Cin, int Cout, int ksize, int stride, int relu, void *workspace,
                           size_t workspace_bytes, void *stream)
 {
-    return conv_run("og_conv2d_bf16", x, w, bias, skip, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
+    return conv_run(OG_LP_STR("og_conv2d"), x, w, bias, skip, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
                     workspace_bytes, stream);
 }
 
-OG_API int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N,
+OG_API int OG_LP_NAME(og_conv2d_proj)(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N,
                                int Hin, int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2,
                                int stride2, int relu, void *workspace, size_t workspace_bytes, void *stream)
 {
-    OG_REQUIRE(x2, OG_EINVAL, "og_conv2d_proj_bf16: null pointer");
+    OG_REQUIRE(x2, OG_EINVAL, "og_conv2d_proj: null pointer");
     Proj pj;
     pj.x2 = x2; pj.H2 = H2; pj.W2 = W2; pj.Cin2 = Cin2; pj.stride2 = stride2;
-    return conv_run("og_conv2d_proj_bf16", x, w_cat, bias, nullptr, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
+    return conv_run(OG_LP_STR("og_conv2d_proj"), x, w_cat, bias, nullptr, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
                     workspace_bytes, stream, pj);
 }

@@ -7,20 +7,15 @@
 //   residual.forward     (models/hourglass_104.py:70-79):  relu(conv2 + b2 + skip)
 //   kp_module.forward    (models/hourglass_104.py:183-190): up1 + nearest_x2(low3)
 // in one in-place pass, 16 B (8 x bf16) per lane, fp32 arithmetic, one rounding to bf16.
+#include "lp_dtype.h"
 #include "og_common.h"
 
 namespace {
 
 typedef unsigned short v8u16 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    // round-to-nearest-even on the bit pattern; activations here are finite
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ float bf2f(unsigned short u) { return lp2f(u); }            // (bf16, or fp16 in the -DOG_DT_F16 build)
+__device__ __forceinline__ unsigned short f2bf(float f) { return f2lp(f); }
 
 template <bool SKIP, bool RELU>
 __global__ void __launch_bounds__(256)
@@ -74,9 +69,9 @@ unsigned grid_for(long groups)
 
 }  // namespace
 
-OG_API int og_bias_act_bf16(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream)
+OG_API int OG_LP_NAME(og_bias_act)(void *x, const float *bias, const void *skip, long pixels, int channels, int relu, void *stream)
 {
-    const char *name = "og_bias_act_bf16";
+    const char *name = OG_LP_STR("og_bias_act");
     OG_REQUIRE(x && bias, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(pixels > 0 && channels > 0 && channels % 8 == 0, OG_EINVAL, "%s: channels must be a multiple of 8", name);
     OG_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)bias % 16 == 0 && (uintptr_t)skip % 16 == 0, OG_EINVAL,
@@ -95,9 +90,9 @@ OG_API int og_bias_act_bf16(void *x, const float *bias, const void *skip, long p
     return OG_OK;
 }
 
-OG_API int og_upsample2_add_bf16(void *up, const void *low, long n, int H, int W, int channels, void *stream)
+OG_API int OG_LP_NAME(og_upsample2_add)(void *up, const void *low, long n, int H, int W, int channels, void *stream)
 {
-    const char *name = "og_upsample2_add_bf16";
+    const char *name = OG_LP_STR("og_upsample2_add");
     OG_REQUIRE(up && low, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(n > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && channels % 8 == 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE((uintptr_t)up % 16 == 0 && (uintptr_t)low % 16 == 0, OG_EINVAL, "%s: pointers must be 16-byte aligned", name);
@@ -143,9 +138,16 @@ nhwc_slice_to_nchw_f32_kernel(const unsigned short *__restrict__ src, int src_c,
 
 }  // namespace
 
-OG_API int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, int H, int W, void *stream)
+#ifdef OG_DT_F16
+#define og_nchw_f32_to_nhwc_lp og_nchw_f32_to_nhwc_f16
+#define og_nhwc_lp_to_nchw_f32 og_nhwc_f16_to_nchw_f32
+#else
+#define og_nchw_f32_to_nhwc_lp og_nchw_f32_to_nhwc_bf16
+#define og_nhwc_lp_to_nchw_f32 og_nhwc_bf16_to_nchw_f32
+#endif
+OG_API int og_nchw_f32_to_nhwc_lp(const float *src, void *dst, long N, int C, int H, int W, void *stream)
 {
-    const char *name = "og_nchw_f32_to_nhwc_bf16";
+    const char *name = OG_LP_STR("og_nchw_f32_to_nhwc");
     OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE(C == 3, OG_EUNSUPPORTED, "%s: only 3-channel images", name);
@@ -156,10 +158,10 @@ OG_API int og_nchw_f32_to_nhwc_bf16(const float *src, void *dst, long N, int C, 
     return OG_OK;
 }
 
-OG_API int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
+OG_API int og_nhwc_lp_to_nchw_f32(const void *src, int src_channels, int first_channel, int channels, const float *bias,
                                     float *dst, long N, int H, int W, void *stream)
 {
-    const char *name = "og_nhwc_bf16_to_nchw_f32";
+    const char *name = "og_nhwc_" OG_LP_STR("") "_to_nchw_f32";
     OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && H > 0 && W > 0 && channels > 0 && first_channel >= 0 && first_channel + channels <= src_channels,
                OG_EINVAL, "%s: bad shape", name);
@@ -199,6 +201,7 @@ center_pad_normalize_kernel(const unsigned char *__restrict__ img, int h, int w,
 
 }  // namespace
 
+#ifndef OG_DT_F16   // not 16-bit-type specific: exists once, in the bf16 build
 OG_API int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int target_h, int target_w, const float *mean3,
                                       const float *std3, const float *fill3, float *out, int *ltrb, void *stream)
 {
@@ -216,3 +219,4 @@ OG_API int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, in
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
+#endif

@@ -13,11 +13,12 @@
 //     each other's load and compute phases;
 //   * epilogue as in the 3x3 kernels: bias + ReLU + one rounding in registers, bf16 tile through LDS, 256-B
 //     contiguous stores.
+#include "lp_dtype.h"
 #include "og_common.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef lp8 bf16x8;   // 8 x 16-bit operands of one MFMA fragment (lp_dtype.h)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -29,12 +30,7 @@ constexpr int kWBytes = kCout * kWPitch, kInBytes = kInH * kInW * 8;
 constexpr int kOPitch = kCout * 2 + 16;
 static_assert(256 * kOPitch <= kWBytes + kInBytes, "output staging reuses the operand LDS");
 
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return f2lp(f); }   // (bf16, or fp16 in the -DOG_DT_F16 build)
 
 __global__ void __launch_bounds__(256, 2)
 stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__ wp, const float *__restrict__ bias,
@@ -98,7 +94,7 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[nn][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], pf[m], acc[nn][m], 0, 0, 0);
+                for (int m = 0; m < 4; ++m) acc[nn][m] = OG_LP_MFMA(wf[nn], pf[m], acc[nn][m]);
         }
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {  // bias + ReLU + the one rounding
@@ -135,10 +131,10 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
 
 }  // namespace
 
-OG_API int og_stem7x7_bf16(const float *images, const void *w_packed, const float *bias, void *out, int N, int H, int W,
+OG_API int OG_LP_NAME(og_stem7x7)(const float *images, const void *w_packed, const float *bias, void *out, int N, int H, int W,
                            int relu, void *stream)
 {
-    const char *name = "og_stem7x7_bf16";
+    const char *name = OG_LP_STR("og_stem7x7");
     OG_REQUIRE(images && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OG_EINVAL, "%s: H, W must be multiples of 32", name);
     OG_REQUIRE((uintptr_t)w_packed % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)bias % 16 == 0, OG_EINVAL,

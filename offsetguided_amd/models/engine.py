@@ -55,7 +55,7 @@ def _epilogue(y, bias32, bias_lp, skip, relu, fused):
         if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
             skip = skip.contiguous(memory_format=torch.channels_last)
         lib = _lib.load()
-        _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias32), _lib.ptr(skip) if skip is not None else None,
+        _lib.check(_lib.lp(lib, 'og_bias_act', y.dtype)(_lib.ptr(y), _lib.ptr(bias32), _lib.ptr(skip) if skip is not None else None,
                                         n * h * w, c, int(relu), _lib.stream_ptr(y.device)), lib)
         return y
     y += bias_lp.view(1, -1, 1, 1)
@@ -133,7 +133,7 @@ class _Conv:
         out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
                           memory_format=torch.channels_last)
         ws = _conv3x3_workspace(x.device, lib.og_conv2d_workspace_bytes(n, h, w, c, cout, 3, st))
-        _lib.check(lib.og_conv2d_bf16(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
+        _lib.check(_lib.lp(lib, 'og_conv2d', x.dtype)(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
                                       _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout, 3, st,
                                       int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
         return out
@@ -172,7 +172,7 @@ class _Residual:
         lib = _lib.load()
         out = torch.empty((n, cout, h, w), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
         ws = _conv3x3_workspace(y.device, lib.og_conv2d_proj_workspace_bytes(n, h, w, c, cout, 3, 1, c2))
-        _lib.check(lib.og_conv2d_proj_bf16(_lib.ptr(y), _lib.ptr(self.w_cat), _lib.ptr(self.c2.b32), _lib.ptr(x), _lib.ptr(out),
+        _lib.check(_lib.lp(lib, 'og_conv2d_proj', y.dtype)(_lib.ptr(y), _lib.ptr(self.w_cat), _lib.ptr(self.c2.b32), _lib.ptr(x), _lib.ptr(out),
                                            n, h, w, c, cout, 3, 1, h2, w2, c2, st2, 1, _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr(y.device)), lib)
         return out
@@ -222,7 +222,7 @@ class _Level:
         if self.fused:  # up += nearest_x2(low) in one pass
             n, c, h, w = up.shape
             lib = _lib.load()
-            _lib.check(lib.og_upsample2_add_bf16(_lib.ptr(up), _lib.ptr(low), n, h, w, c, _lib.stream_ptr(up.device)), lib)
+            _lib.check(_lib.lp(lib, 'og_upsample2_add', up.dtype)(_lib.ptr(up), _lib.ptr(low), n, h, w, c, _lib.stream_ptr(up.device)), lib)
         else:
             up += F.interpolate(low, scale_factor=2, mode='nearest')
         return up
@@ -249,8 +249,8 @@ class InferenceEngine:
         _build_device = self.device
         dev_model = model
         assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
-        # hand-written HIP epilogues (bias/ReLU/residual add, upsample+add) on the GPU bf16 path
-        fused = self.fused = (self.device.type == 'cuda' and dtype == torch.bfloat16)
+        # hand-written HIP kernels on the GPU 16-bit paths (bf16, or fp16 = the reference's apex-O2 arithmetic)
+        fused = self.fused = (self.device.type == 'cuda' and dtype in (torch.bfloat16, torch.float16))
         self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype, fused), _Residual(net.pre[1], dtype, fused)]
         self.kps = [_Level(net.kps[s], dtype, fused) for s in range(self.stage + 1)]
         self.cnvs = [_Conv(net.cnvs[s].conv, net.cnvs[s].bn, True, dtype, fused) for s in range(self.stage + 1)]
@@ -307,7 +307,7 @@ class InferenceEngine:
             images = images.float().contiguous()
             n, c, h, w = images.shape
             x = torch.empty((n, 128, h // 2, w // 2), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
-            _lib.check(lib.og_stem7x7_bf16(_lib.ptr(images), _lib.ptr(self.stem_w), _lib.ptr(self.pre[0].b32), _lib.ptr(x),
+            _lib.check(_lib.lp(lib, 'og_stem7x7', self.dtype)(_lib.ptr(images), _lib.ptr(self.stem_w), _lib.ptr(self.pre[0].b32), _lib.ptr(x),
                                            n, h, w, 1, _lib.stream_ptr(images.device)), lib)
             inter = self.pre[1](x)
         else:
@@ -316,7 +316,7 @@ class InferenceEngine:
                 images = images.float().contiguous()
                 n, c, h, w = images.shape
                 x = torch.empty((n, c, h, w), dtype=self.dtype, device=images.device, memory_format=torch.channels_last)
-                _lib.check(lib.og_nchw_f32_to_nhwc_bf16(_lib.ptr(images), _lib.ptr(x), n, c, h, w, _lib.stream_ptr(images.device)), lib)
+                _lib.check(_lib.lp(lib, 'og_nchw_f32_to_nhwc', self.dtype)(_lib.ptr(images), _lib.ptr(x), n, c, h, w, _lib.stream_ptr(images.device)), lib)
             else:
                 x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
             inter = _run(self.pre, x)
@@ -332,7 +332,7 @@ class InferenceEngine:
             outs, c0 = [], 0
             for ch in self.head_channels:
                 o = torch.empty((n, ch, h, w), dtype=torch.float32, device=y.device)
-                _lib.check(lib.og_nhwc_bf16_to_nchw_f32(_lib.ptr(y), cc, c0, ch, _lib.ptr(self.heads_b), _lib.ptr(o), n, h, w,
+                _lib.check((lib.og_nhwc_f16_to_nchw_f32 if y.dtype == torch.float16 else lib.og_nhwc_bf16_to_nchw_f32)(_lib.ptr(y), cc, c0, ch, _lib.ptr(self.heads_b), _lib.ptr(o), n, h, w,
                                                         _lib.stream_ptr(y.device)), lib)
                 outs.append(o)
                 c0 += ch

@@ -220,7 +220,7 @@ def _pose_keypoints(poses):
     return out
 
 
-@pytest.mark.parametrize("dtype,min_common", [(torch.bfloat16, 0.90), (torch.float32, 0.999)])
+@pytest.mark.parametrize("dtype,min_common", [(torch.bfloat16, 0.90), (torch.float16, 0.98), (torch.float32, 0.999)])
 def test_engine_precision_at_the_pose_level(dev, dtype, min_common):
     """Key-seeded weights + a planted signal (synthetic persons added to the head outputs, as bench.py does): poses decoded
     from the engine's maps vs poses decoded from the eager fp32 module's maps.  Grouping is bit-identical GIVEN identical
@@ -262,4 +262,4 @@ def test_engine_precision_at_the_pose_level(dev, dtype, min_common):
           f'{common}/{tot} keypoints at identical pixels, planted {strong_common}/{strong}, max |dscore| {dscore:.2e}')
     assert strong > 20 and strong_common >= 0.95 * strong
     assert common >= min_common * tot
-    assert dscore <= (2e-3 if dtype == torch.bfloat16 else 1e-5)
+    assert dscore <= {torch.bfloat16: 2e-3, torch.float16: 3e-4, torch.float32: 1e-5}[dtype]
