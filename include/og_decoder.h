@@ -205,6 +205,18 @@ int og_nhwc_bf16_to_nchw_f32(const void *src, int src_channels, int first_channe
 int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int target_h, int target_w, const float *mean3,
                                const float *std3, const float *fill3, float *out, int *ltrb, void *stream);
 
+/* RescaleLongAbsolute's cv2.resize(INTER_CUBIC) (transforms/scale.py:27) for (h,w,3) uint8 images in HBM -> (new_h,new_w,3).
+ * OpenCV's published 8-bit algorithm (fixed-point taps, replicated border); pinned bit-exactly to the CPU restatement
+ * oracle/og_oracle.c:ogo_resize_cubic_u8 -- parity with cv2 itself is unpinned (third-party, absent from the build). */
+int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int new_h, int new_w, void *stream);
+
+/* The whole input chain of evaluate.py:157-168 in one pass: rescale to (new_h,new_w) as above, CenterPad to
+ * (target_h,target_w) with the fill colour, ToTensor, Normalize -> out fp32 (3,target_h,target_w); ltrb as
+ * og_center_pad_normalize_u8.  The resized uint8 image is never stored. */
+int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, int new_h, int new_w, int target_h, int target_w,
+                                const float *mean3, const float *std3, const float *fill3, float *out, int *ltrb,
+                                void *stream);
+
 /* ---- network stem: convolution(7, 3, 128, stride=2) + BN + ReLU  models/hourglass_104.py:283, :16-30 ----
  * images (N,3,H,W) fp32 (H, W multiples of 32) -> out (N,H/2,W/2,128) bf16 NHWC, input conversion and epilogue fused.
  * w_packed bf16 [128][7 kernel rows][8 taps][4 channels] (tap 7 and channel 3 zero) = the BN-folded weight

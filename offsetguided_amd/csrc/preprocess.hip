@@ -1,0 +1,133 @@
+// Input side of evaluate.py on the device: RescaleLongAbsolute -> CenterPad -> ToTensor -> Normalize
+// (evaluate.py:157-168; transforms/scale.py:14-31,75-98; transforms/pad.py:35-62) for a uint8 HWC image already in HBM,
+// as ONE pass that writes the fp32 NCHW network input -- the resized uint8 image is never stored.
+//
+// The rescale is cv2.resize(..., INTER_CUBIC) in the reference.  cv2 is a third-party dependency that is absent from the
+// build container (opencv-python==3.4.5.20, requirment.txt:91), so this kernel follows OpenCV's PUBLISHED algorithm for
+// 8-bit images (resize.cpp: fixed-point taps round(w * 2048), int horizontal pass over clamped taps, vertical pass,
+// (sum + 2^21) >> 22, saturate) and is pinned bit-exactly to oracle/og_oracle.c:ogo_resize_cubic_u8, the same restatement
+// on the CPU -- parity with cv2 itself is UNPINNED (no golden vector can be generated here).
+// One thread per output pixel: 16 taps x 3 channels from L2 (the source image is read ~once from HBM), coefficients
+// recomputed per thread in the float arithmetic of interpolateCubic (explicit operation order, -ffp-contract=off).
+#include <math.h>
+
+#include "og_common.h"
+
+namespace {
+
+struct Taps {
+    int i0;       // index of the first tap (s - 1), unclamped
+    int t[4];     // fixed-point weights, sum ~ 2048
+};
+
+__device__ __forceinline__ Taps cubic_taps(int d, double scale)
+{
+    const float f = (float)((d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    const float x = f - (float)s;
+    const float A = -0.75f;
+    float c[4];
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+    Taps r;
+    r.i0 = s - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.t[k] = min(max(__float2int_rn(c[k] * 2048.f), -32768), 32767);   // saturate_cast<short>
+    return r;
+}
+
+// resized pixel (dy, dx) of an (h, w, 3) uint8 image scaled to (nh, nw): three channels
+__device__ __forceinline__ void resized_px(const unsigned char *__restrict__ src, int h, int w, double sy, double sx, int dy, int dx,
+                                           int (&out)[3])
+{
+    const Taps ty = cubic_taps(dy, sy), tx = cubic_taps(dx, sx);
+    int xi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xi[k] = min(max(tx.i0 + k, 0), w - 1) * 3;
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned char *row = src + (size_t)min(max(ty.i0 + r, 0), h - 1) * w * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int hs = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hs += (int)row[xi[k] + c] * tx.t[k];
+            acc[c] += hs * ty.t[r];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = min(max((acc[c] + (1 << 21)) >> 22, 0), 255);
+}
+
+__global__ void __launch_bounds__(256)
+resize_cubic_kernel(const unsigned char *__restrict__ src, int h, int w, unsigned char *__restrict__ dst, int nh, int nw,
+                    double sy, double sx)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nh * nw) return;
+    int v[3];
+    resized_px(src, h, w, sy, sx, (int)(i / nw), (int)(i % nw), v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (unsigned char)v[c];
+}
+
+struct PrepArgs {
+    float mean[3], stdv[3], fill[3];
+};
+
+__global__ void __launch_bounds__(256)
+rescale_pad_normalize_kernel(const unsigned char *__restrict__ src, int h, int w, int nh, int nw, double sy, double sx, int left,
+                             int top, int TH, int TW, PrepArgs a, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)TH * TW) return;
+    const int X = (int)(i % TW), Y = (int)(i / TW);
+    const int x = X - left, y = Y - top;
+    float v[3] = {a.fill[0], a.fill[1], a.fill[2]};
+    if (x >= 0 && x < nw && y >= 0 && y < nh) {
+        int p[3];
+        resized_px(src, h, w, sy, sx, y, x, p);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)c * TH * TW + i] = (v[c] / 255.f - a.mean[c]) / a.stdv[c];   // ToTensor, Normalize
+}
+
+}  // namespace
+
+OG_API int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int new_h, int new_w, void *stream)
+{
+    const char *name = "og_resize_cubic_u8";
+    OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(h > 0 && w > 0 && new_h > 0 && new_w > 0 && (long)h * w < (1l << 28) && (long)new_h * new_w < (1l << 28), OG_EINVAL,
+               "%s: bad shape", name);
+    const long total = (long)new_h * new_w;
+    hipLaunchKernelGGL(resize_cubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, h, w, dst,
+                       new_h, new_w, (double)h / new_h, (double)w / new_w);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, int new_h, int new_w, int target_h, int target_w,
+                                       const float *mean3, const float *std3, const float *fill3, float *out, int *ltrb,
+                                       void *stream)
+{
+    const char *name = "og_rescale_pad_normalize_u8";
+    OG_REQUIRE(img && mean3 && std3 && fill3 && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(h > 0 && w > 0 && new_h > 0 && new_w > 0 && (long)h * w < (1l << 28), OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(target_h >= new_h && target_w >= new_w, OG_EINVAL, "%s: the rescaled image must fit the target", name);
+    // transforms/pad.py:43-55: left = int((T - w) / 2.0), top likewise; the rest goes right / down
+    const int left = (int)((target_w - new_w) / 2.0), top = (int)((target_h - new_h) / 2.0);
+    if (ltrb) { ltrb[0] = left; ltrb[1] = top; ltrb[2] = target_w - new_w - left; ltrb[3] = target_h - new_h - top; }
+    PrepArgs a;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; a.fill[c] = fill3[c]; }
+    const long total = (long)target_h * target_w;
+    hipLaunchKernelGGL(rescale_pad_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       h, w, new_h, new_w, (double)h / new_h, (double)w / new_w, left, top, target_h, target_w, a, out);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

@@ -1,0 +1,121 @@
+"""RescaleLongAbsolute / RescaleHighAbsolute (transforms/scale.py:75-125) and the whole evaluate.py:157-168 input chain on
+the device.
+
+`rescale_size` and `rescale_meta` restate the reference's bookkeeping (target size from the long edge; x/y scale factors
+(w' - 1) / (w - 1), keypoint scales * sqrt(sx * sy); meta offset / scale / valid_area updates, transforms/scale.py:33-71).
+`EvalPreprocess` is the chain NormalizeAnnotations' meta -> RescaleLongAbsolute -> CenterPad -> ToTensor -> Normalize: the
+uint8 image goes to the device through a pinned staging buffer and ONE kernel (og_rescale_pad_normalize_u8) writes its
+slot of the fp32 batch tensor.  The interpolation is OpenCV's published INTER_CUBIC algorithm for 8-bit images; it is
+pinned to the CPU restatement in oracle/, parity with cv2 itself is unpinned (cv2 is not available offline)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..config import data_mean, data_std
+from .pad import FILL
+
+
+def rescale_size(w, h, long_edge, fixed_height=False):
+    """(target_w, target_h) of RescaleLongAbsolute (transforms/scale.py:91-97) / RescaleHighAbsolute (:118-121)."""
+    if fixed_height:
+        s = long_edge / h
+        return int(w * s), long_edge
+    s = long_edge / max(h, w)
+    return (int(w * s), long_edge) if h > w else (long_edge, int(h * s))
+
+
+def initial_meta(w, h, image_id=None):
+    """The meta NormalizeAnnotations creates for an untouched image (transforms/annotations.py:68-80)."""
+    return {'image_id': image_id, 'offset': np.array([0.0, 0.0]), 'scale': np.array([1.0, 1.0]),
+            'valid_area': np.array([0.0, 0.0, w, h]), 'hflip': False, 'width_height': np.array([w, h])}
+
+
+def rescale_meta(meta, anns, w, h, target_w, target_h):
+    """Meta / annotation updates of _scale (transforms/scale.py:33-71); returns (meta, anns), inputs untouched."""
+    x_scale, y_scale = (target_w - 1) / (w - 1), (target_h - 1) / (h - 1)
+    meta = {k: (np.array(v, dtype=np.float64) if isinstance(v, np.ndarray) else v) for k, v in meta.items()}
+    factors = np.array((x_scale, y_scale))
+    meta['offset'] = meta['offset'] * factors
+    meta['scale'] = meta['scale'] * factors
+    meta['width_height'] = np.array([target_w, target_h])
+    meta['valid_area'] = meta['valid_area'].copy()
+    meta['valid_area'][:2] *= factors
+    meta['valid_area'][2:] *= factors
+    if anns is not None and len(anns):
+        anns = np.array(anns, dtype=np.float32, copy=True)
+        anns[:, :, 0] *= x_scale
+        anns[:, :, 1] *= y_scale
+        anns[:, :, 3] *= math.sqrt(x_scale * y_scale)
+    return meta, anns
+
+
+def resize_cubic(image, new_h, new_w, device='cuda:0'):
+    """cv2.resize(image, (new_w, new_h), INTER_CUBIC) of one (h, w, 3) uint8 image on the device -> uint8 tensor."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    t = torch.as_tensor(np.ascontiguousarray(image) if isinstance(image, np.ndarray) else image)
+    t = _lib.require_device(t.to(dev), 'image', torch.uint8)
+    assert t.dim() == 3 and t.shape[2] == 3, 'images are (h, w, 3) uint8 RGB'
+    out = torch.empty((new_h, new_w, 3), dtype=torch.uint8, device=dev)
+    _lib.check(lib.og_resize_cubic_u8(_lib.ptr(t), int(t.shape[0]), int(t.shape[1]), _lib.ptr(out), new_h, new_w,
+                                      _lib.stream_ptr(dev)), lib)
+    return out
+
+
+class EvalPreprocess:
+    """images: list of (h, w, 3) uint8 RGB arrays of any size -> ((N, 3, T, T) fp32 on the device, metas) with the metas
+    `annotations_inverse` needs (offset, scale) after rescale + centre pad.  Host images are staged through two pinned
+    buffers and copied asynchronously; batch i+1 can be prepared while batch i is in the network."""
+
+    def __init__(self, long_edge, device='cuda:0', mean=data_mean, std=data_std, fill=FILL, fixed_height=False):
+        self.long_edge, self.device, self.fixed_height = long_edge, torch.device(device), fixed_height
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+        self._mean, self._std, self._fill = f3(mean), f3(std), f3(fill)
+        self._stage, self._turn = [None, None], 0
+        self.copy_stream = torch.cuda.Stream(self.device)
+
+    def _staging(self, nbytes):
+        buf = self._stage[self._turn]
+        if buf is None or buf[0].numel() < nbytes:
+            buf = self._stage[self._turn] = [torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8).pin_memory(), None]
+        if buf[1] is not None:
+            buf[1].synchronize()          # the copies that last used this staging buffer have left the host
+        self._turn ^= 1
+        return buf
+
+    def __call__(self, images, image_ids=None):
+        lib = _lib.load()
+        T = self.long_edge
+        sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+        total = sum(h * w * 3 for h, w in sizes)
+        stage = self._staging(total)
+        dev_raw = torch.empty(total, dtype=torch.uint8, device=self.device)
+        o = 0
+        for im, (h, w) in zip(images, sizes):          # pack the batch into ONE pinned buffer: one H2D copy
+            assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'images are (h, w, 3) uint8 RGB'
+            stage[0][o:o + h * w * 3].copy_(torch.from_numpy(np.ascontiguousarray(im)).reshape(-1))
+            o += h * w * 3
+        with torch.cuda.stream(self.copy_stream):
+            dev_raw.copy_(stage[0][:total], non_blocking=True)
+            stage[1] = torch.cuda.Event()
+            stage[1].record(self.copy_stream)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.copy_stream)
+        dev_raw.record_stream(cur)
+        out = torch.empty((len(images), 3, T, T), dtype=torch.float32, device=self.device)
+        metas, o = [], 0
+        for i, (h, w) in enumerate(sizes):
+            tw, th = rescale_size(w, h, T, self.fixed_height)
+            ltrb = (C.c_int * 4)()
+            _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, T, T, self._mean, self._std,
+                                                       self._fill, _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
+            o += h * w * 3
+            meta, _ = rescale_meta(initial_meta(w, h, None if image_ids is None else image_ids[i]), None, w, h, tw, th)
+            meta['offset'] = meta['offset'] - np.array(ltrb[:2], np.float64)          # CenterPad, transforms/pad.py:28-31
+            meta['valid_area'][:2] += np.array(ltrb[:2], np.float64)
+            meta['width_height'] = np.array([T, T])
+            metas.append(meta)
+        return out, metas

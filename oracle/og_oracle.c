@@ -781,3 +781,58 @@ OGO_API void ogo_encode_offsets(const float *joints, int P, int n_kp, const int 
             }
         }
 }
+
+/* ---- transforms/scale.py:14-31, :75-98 (RescaleLongAbsolute -> cv2.resize(image, (w, h), INTER_CUBIC)) ----
+ * THIRD-PARTY ARITHMETIC, PARITY UNPINNED: cv2 (opencv-python==3.4.5.20, requirment.txt:91) is absent from the build
+ * container and not vendored by the reference, so no golden vector exists.  This restates the published algorithm of
+ * cv::resize for 8-bit images (OpenCV 3.4 modules/imgproc/src/resize.cpp: resizeGeneric_ with HResizeCubic<uchar,int,short>
+ * and VResizeCubic<uchar,int,short,FixedPtCast<int,uchar,22>>):
+ *   scale = src / dst (double); per destination index d: f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s;
+ *   cubic weights (A = -0.75) in float, fixed-point taps = round-half-even(w * 2048) as short;
+ *   horizontal pass in int over taps s-1 .. s+2 (indices clamped to the image = replicated border);
+ *   vertical pass over rows s-1 .. s+2 (clamped), result = saturate_u8((sum + 2^21) >> 22).
+ * (OpenCV's SSE2 vertical pass evaluates the same sum in float and rounds to nearest even, which can differ from this
+ * fixed-point definition by one grey level in rare pixels; neither can be checked here.) */
+static void ogo_cubic_taps(float x, short *t)
+{
+    const float A = -0.75f;
+    float c[4];
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+    for (int k = 0; k < 4; ++k) {
+        long v = lrintf(c[k] * 2048.f); /* saturate_cast<short>(float): cvRound, round half to even */
+        t[k] = (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+    }
+}
+
+static int ogo_clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+OGO_API void ogo_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int nh, int nw)
+{
+    const double sx = (double)w / nw, sy = (double)h / nh;
+    for (int dy = 0; dy < nh; ++dy) {
+        float fy = (float)((dy + 0.5) * sy - 0.5);
+        const int y0 = (int)floorf(fy);
+        short by[4];
+        ogo_cubic_taps(fy - (float)y0, by);
+        for (int dx = 0; dx < nw; ++dx) {
+            float fx = (float)((dx + 0.5) * sx - 0.5);
+            const int x0 = (int)floorf(fx);
+            short ax[4];
+            ogo_cubic_taps(fx - (float)x0, ax);
+            for (int c = 0; c < 3; ++c) {
+                int acc = 0;
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned char *row = src + (size_t)ogo_clampi(y0 - 1 + r, 0, h - 1) * w * 3;
+                    int hs = 0;
+                    for (int k = 0; k < 4; ++k) hs += row[ogo_clampi(x0 - 1 + k, 0, w - 1) * 3 + c] * ax[k];
+                    acc += hs * by[r];
+                }
+                const int v = (acc + (1 << 21)) >> 22;
+                dst[((size_t)dy * nw + dx) * 3 + c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+    }
+}

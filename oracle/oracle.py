@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "libog_oracle.so")
 
 __all__ = [
     "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
-    "greedy_group", "group_stats", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "encode_jitter", "decode",
+    "greedy_group", "group_stats", "resize_cubic_u8", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "encode_jitter", "decode",
 ]
 
 _lib = None
@@ -67,6 +67,8 @@ def lib():
         L.ogo_greedy_group.restype = C.c_int
         L.ogo_flip_merge.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      _I32, _I32, _I32, C.c_int, _F, _F]
+        L.ogo_resize_cubic_u8.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int,
+                                          np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int]
         L.ogo_group_stats.argtypes = [np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), C.c_int]
         _lib = L
     return _lib
@@ -235,6 +237,15 @@ def encode_offsets(joints, skeleton, sigmas, in_w, in_h, stride=4, fill_size=7, 
     lib().ogo_encode_offsets(joints, p, n_kp, jf, jt, L, in_w, in_h, stride, fill_size, min_jscale,
                              np.asarray(sigmas, np.float32), off, sc, ps)
     return off, sc, ps
+
+
+def resize_cubic_u8(img, new_h, new_w):
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_CUBIC) for (h, w, 3) uint8 images, restated from OpenCV's
+    published fixed-point algorithm (transforms/scale.py:27; PARITY UNPINNED: cv2 is absent, see og_oracle.c)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((new_h, new_w, 3), np.uint8)
+    lib().ogo_resize_cubic_u8(img, img.shape[0], img.shape[1], out, new_h, new_w)
+    return out
 
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,

@@ -37,3 +37,77 @@ def test_center_pad_normalize_bit_exact():
         assert torch.equal(got, ref)
         assert tuple(meta['offset']) == (-left, -top) and tuple(meta['valid_area'][:2]) == (left, top)
         assert tuple(meta['width_height']) == (640, 640)
+
+
+def test_rescale_size_and_meta_follow_the_reference_formulas():
+    # transforms/scale.py:91-97: the long edge becomes long_edge, the other one int(edge * s)
+    assert transforms.rescale_size(640, 427, 640) == (640, 427)
+    assert transforms.rescale_size(500, 375, 640) == (640, 480)
+    assert transforms.rescale_size(375, 500, 640) == (480, 640)
+    assert transforms.rescale_size(333, 1000, 640) == (213, 640)
+    assert transforms.rescale_size(500, 375, 640, fixed_height=True) == (853, 640)
+    meta = transforms.initial_meta(500, 375, image_id=7)
+    anns = np.zeros((1, 17, 4), np.float32)
+    anns[0, :, 0], anns[0, :, 1], anns[0, :, 3] = 100.0, 50.0, 8.0
+    m2, a2 = transforms.rescale_meta(meta, anns, 500, 375, 640, 480)
+    sx, sy = 639 / 499, 479 / 374                                    # (w' - 1) / (w - 1), transforms/scale.py:37-38
+    assert np.allclose(m2['scale'], [sx, sy]) and np.allclose(m2['offset'], [0, 0]) and tuple(m2['width_height']) == (640, 480)
+    assert np.allclose(m2['valid_area'], [0, 0, 500 * sx, 375 * sy])
+    assert np.allclose(a2[0, 0], [100 * sx, 50 * sy, 0, 8 * np.sqrt(sx * sy)], rtol=1e-6)
+    assert tuple(meta['scale']) == (1.0, 1.0) and anns[0, 0, 0] == 100.0       # inputs untouched
+    # ... and annotations_inverse undoes rescale + centre pad
+    from offsetguided_amd.evaluate import annotations_inverse
+    m2['offset'] = m2['offset'] - np.array([0.0, 80.0])
+    kp = np.zeros((1, 17, 6), np.float32)
+    kp[0, :, 0], kp[0, :, 1], kp[0, :, 3] = 100 * sx, 50 * sy + 80, 8 * np.sqrt(sx * sy)
+    back = annotations_inverse(kp, m2)
+    assert np.allclose(back[0, 0, :2], [100, 50], atol=1e-4) and np.allclose(back[0, 0, 3], 8, atol=1e-5)
+
+
+def test_resize_restatement_properties():
+    """The CPU restatement of cv2.resize(INTER_CUBIC) (parity with cv2 unpinned): identity at equal size, constant images
+    stay constant, a x2 enlargement of a ramp stays monotone inside, replicated borders."""
+    import oracle
+    rng = np.random.default_rng(1)
+    im = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    assert (oracle.resize_cubic_u8(im, 9, 13) == im).all()
+    assert (oracle.resize_cubic_u8(np.full((7, 5, 3), 201, np.uint8), 19, 11) == 201).all()
+    ramp = np.tile(np.arange(0, 240, 12, dtype=np.uint8)[None, :, None], (6, 1, 3))
+    up = oracle.resize_cubic_u8(ramp, 12, 40).astype(int)
+    assert (np.diff(up[3, :, 0]) >= 0).all() and up[3, 0, 0] <= 2 and up[3, -1, 0] >= 225
+    down = oracle.resize_cubic_u8(rng.integers(0, 256, (64, 48, 3), dtype=np.uint8), 21, 16)
+    assert down.shape == (21, 16, 3)
+
+
+@pytest.mark.gpu
+def test_resize_and_fused_chain_bit_exact_vs_restatement():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    import oracle
+    rng = np.random.default_rng(2)
+    cases = [((427, 640), 640), ((640, 480), 640), ((375, 500), 640), ((1000, 333), 640), ((31, 17), 128), ((640, 640), 640),
+             ((240, 320), 512)]
+    images = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w), _ in cases]
+    mean, std = torch.tensor(data_mean).view(3, 1, 1), torch.tensor(data_std).view(3, 1, 1)
+    for im, ((h, w), T) in zip(images, cases):
+        tw, th = transforms.rescale_size(w, h, T)
+        ref = oracle.resize_cubic_u8(im, th, tw)
+        got = transforms.resize_cubic(im, th, tw).cpu().numpy()
+        assert (got == ref).all(), (h, w, T)
+        pre = transforms.EvalPreprocess(T)
+        out, metas = pre([im], image_ids=[5])
+        left, top, _, _ = transforms.center_pad_ltrb(tw, th, T, T)
+        canvas = np.empty((T, T, 3), np.uint8)
+        canvas[:] = np.array(transforms.pad.FILL, np.uint8)
+        canvas[top:top + th, left:left + tw] = ref
+        expect = (torch.from_numpy(canvas).permute(2, 0, 1).float().div(255) - mean) / std
+        assert torch.equal(out[0].cpu(), expect)
+        sx, sy = (tw - 1) / (w - 1), (th - 1) / (h - 1)
+        assert np.allclose(metas[0]['scale'], [sx, sy]) and np.allclose(metas[0]['offset'], [-left, -top])
+        assert metas[0]['image_id'] == 5
+    pre = transforms.EvalPreprocess(640)
+    for _ in range(3):                                           # a batch of mixed sizes, staging buffers reused
+        out, metas = pre(images[:4])
+        assert out.shape == (4, 3, 640, 640) and len(metas) == 4
+        single, _ = pre([images[2]])
+        assert torch.equal(out[2], single[0])
