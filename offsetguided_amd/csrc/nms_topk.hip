@@ -370,7 +370,11 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 #define s_tau (*s_tau_p)
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
+#ifdef OG_K1_REVERSE_PLANES   // A/B: read first what K1a wrote last; measured no gain
+    const int plane = total / nbands - 1 - wid / nbands, band = wid % nbands;
+#else
     const int plane = wid / nbands, band = wid % nbands;
+#endif
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
     int q_lane = 0;
