@@ -852,12 +852,10 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
 #define HALO_LAUNCH(TW_, TH_, WM_)                                                                              \
     do {                                                                                                        \
         constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 9 + 511) / 512, lds_ = 2 * npa_ * 8192 + 4 * 128 * 128;   \
-        static bool attr_ = false;                                                                              \
-        if (!attr_) {                                                                                           \
+        static OgAttrOnce attr_;                                                                                \
+        if (attr_.need())                                                                                       \
             (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<TW_, TH_, WM_>,                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
-            attr_ = true;                                                                                       \
-        }                                                                                                       \
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                       \
         hipLaunchKernelGGL((conv3x3_halo_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(512), lds_, st, h); \
     } while (0)
@@ -900,12 +898,10 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
 #define CONV_LAUNCH(BM_, ST_)                                                                                   \
     do {                                                                                                        \
         constexpr int lds_ = ST_ * 2 * BM_ * 128;                                                               \
-        static bool attr_ = false;                                                                              \
-        if (!attr_) {                                                                                           \
+        static OgAttrOnce attr_;                                                                                \
+        if (attr_.need())                                                                                       \
             (void)hipFuncSetAttribute((const void *)conv3x3_kernel<BM_, BM_, ST_>,                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
-            attr_ = true;                                                                                       \
-        }                                                                                                       \
         hipLaunchKernelGGL((conv3x3_kernel<BM_, BM_, ST_>), grid, dim3(256), lds_, st, a);                      \
     } while (0)
     if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);

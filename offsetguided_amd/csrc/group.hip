@@ -458,12 +458,10 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
         a.gsub = (float *)workspace;
     }
     void (*kern)(GroupArgs) = a.gsub ? greedy_group_kernel<true> : greedy_group_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    const int variant = a.gsub ? 1 : 0;
-    if (!attr_set[variant]) {
+    static OgAttrOnce attr_set[2];
+    if (attr_set[a.gsub ? 1 : 0].need()) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-        attr_set[variant] = true;
     }
     hipLaunchKernelGGL(kern, dim3(N), dim3(kThreads), lds, (hipStream_t)stream, a);
     OG_LAUNCH_CHECK(name);

@@ -29,6 +29,22 @@ void og_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 static inline size_t og_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncSetAttribute applies to the CURRENT device: a process that drives several devices must apply it on each one.
+// `static OgAttrOnce once; if (once.need()) hipFuncSetAttribute(...)` remembers it per device ordinal (a repeated call
+// from a racing thread is harmless).
+struct OgAttrOnce {
+    unsigned long long done = 0;
+    bool need()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done & bit) return false;
+        done |= bit;
+        return true;
+    }
+};
+
 // XCD-aware work mapping: hardware deals consecutive workgroup ids round-robin over the 8
 // XCDs, so ids b and b+8 share an L2.  Remap so that CONSECUTIVE work items (bands of one
 // plane, which share halo rows) land on one XCD.  `padded` = grid size (multiple of 8).

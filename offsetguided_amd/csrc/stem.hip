@@ -142,11 +142,8 @@ OG_API int OG_LP_NAME(og_stem7x7)(const float *images, const void *w_packed, con
     const long blocks = (long)N * (H / 32) * (W / 32);
     OG_REQUIRE(blocks < (1l << 31), OG_EINVAL, "%s: too many tiles", name);
     constexpr int lds = kWBytes + kInBytes;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)stem7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    static OgAttrOnce attr;
+    if (attr.need()) (void)hipFuncSetAttribute((const void *)stem7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, images,
                        (const unsigned short *)w_packed, bias, (unsigned short *)out, H, W, relu);
     OG_LAUNCH_CHECK(name);

@@ -77,6 +77,7 @@ CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # st
 BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fork up1 only at levels <= this depth
 _conv_ws = {}
+_WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
 _branch = 0      # which concurrent branch is issuing work: 0 = trunk, d+1 = up1 branch of level d
 _engine = 0      # which InferenceEngine is issuing work (engines may run concurrently on different streams)
 _n_engines = 0
@@ -108,9 +109,31 @@ class _Conv:
                        and tuple(conv.padding) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
 
     def raw(self, x):
+        fake = self._whatif_skipped(x)
+        if fake is not None:
+            return fake
         return F.conv2d(x, self.w, None, self.stride, self.pad)
 
+    def _whatif_skipped(self, x):
+        """OG_ENGINE_WHATIF=<classes> (diagnostic, WRONG RESULTS): layers of the named classes produce an uninitialised
+        output instead of running -- the forward time that disappears is that class's share of the critical path.
+        Classes: s2big (MIOpen stride-2 3x3), 1x1 (MIOpen 1x1), chain (split-K small levels), c160 / c80 / c40 (halo)."""
+        if not _WHATIF:
+            return None
+        n, c, h, w = x.shape
+        st, k = self.stride[0], self.w.shape[2]
+        ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+        pixels = n * ho * wo
+        cls = ('1x1' if k == 1 else 'chain' if pixels <= CONV3X3_MAX_PIXELS else 's2big' if st == 2 else
+               'c160' if ho >= 160 else 'c80' if ho >= 80 else 'c40')
+        if cls not in _WHATIF:
+            return None
+        return torch.empty((n, self.w.shape[0], ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+
     def __call__(self, x, skip=None):
+        fake = self._whatif_skipped(x)
+        if fake is not None:
+            return fake
         n, c, h, w = x.shape
         if self.hip3x3:
             st = self.stride[0]
@@ -159,7 +182,7 @@ class _Residual:
     def __call__(self, x):
         y = self.c1(x)
         n, c, h, w = y.shape
-        if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS:
+        if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS and not _WHATIF:
             return self._proj(y, x)
         shortcut = x if self.skip is None else self.skip.raw(x)
         return self.c2(y, skip=shortcut)
