@@ -21,6 +21,7 @@ Building an engine does not touch the caller's module: the weights are folded fr
 train / eval flag and device stay as they are.
 """
 import os
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -29,7 +30,6 @@ from .. import _lib
 from .hourglass_104 import ConvBlock, HourglassLevel, Residual
 
 
-_build_device = None   # device the folded weights of the engine under construction go to
 
 
 def _fold(conv, bn):
@@ -41,8 +41,8 @@ def _fold(conv, bn):
         scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
         w = w * scale[:, None, None, None]
         b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
-    if _build_device is not None:
-        w, b = w.to(_build_device), b.to(_build_device)
+    if _issuer.build_device is not None:   # the engine under construction on this thread
+        w, b = w.to(_issuer.build_device), b.to(_issuer.build_device)
     return w, b
 
 
@@ -78,15 +78,22 @@ BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fork up1 only at levels <= this depth
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
-_branch = 0      # which concurrent branch is issuing work: 0 = trunk, d+1 = up1 branch of level d
-_engine = 0      # which InferenceEngine is issuing work (engines may run concurrently on different streams)
+class _Issuer(threading.local):
+    """Who is issuing work on THIS host thread (engines may be built / run from several threads and on several
+    streams): the engine id and the concurrent branch (0 = trunk, d+1 = up1 branch of level d) select the scratch."""
+    engine = 0
+    branch = 0
+    build_device = None   # device the folded weights of the engine under construction go to
+
+
+_issuer = _Issuer()
 _n_engines = 0
 
 
 def _conv3x3_workspace(device, nbytes):
     """One zero-initialised scratch per (device, concurrent branch) for og_conv3x3_bf16 (zero page + split-K slabs).
     Layers of one branch run back to back on one stream, so they share it; it only ever grows outside graph capture."""
-    key = (device.index, _engine, _branch)
+    key = (device.index, _issuer.engine, _issuer.branch)
     buf = _conv_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         assert not torch.cuda.is_current_stream_capturing(), 'conv3x3 workspace must be sized before graph capture'
@@ -224,7 +231,6 @@ class _Level:
         return _run(self.low3, low)
 
     def __call__(self, x):
-        global _branch
         if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None:
@@ -232,11 +238,11 @@ class _Level:
                 prio = int(os.environ.get('OG_ENGINE_SIDE_PRIORITY', '0'))
                 self._side = torch.cuda.Stream(x.device, priority=prio)
             self._side.wait_stream(cur)                      # fork: up1 only needs x
-            outer = _branch
+            outer = _issuer.branch
             with torch.cuda.stream(self._side):
-                _branch = self.depth + 1
+                _issuer.branch = self.depth + 1
                 up = _run(self.up1, x)
-                _branch = outer
+                _issuer.branch = outer
             low = self._lower(x)
             cur.wait_stream(self._side)                      # join before the merge
         else:
@@ -259,7 +265,7 @@ class InferenceEngine:
     def __init__(self, model, batch, height, width, dtype=torch.bfloat16, device='cuda:0', feat_stage=-1,
                  use_graph=True):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
-        global _n_engines, _build_device
+        global _n_engines
         self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
         _n_engines += 1
         self.device = torch.device(device)
@@ -269,7 +275,7 @@ class InferenceEngine:
         self.n_stacks = net.nstack
         self.stage = feat_stage % self.n_stacks
         # the caller's module is only read: weights are folded from it onto the engine's device (no .to(), no .eval())
-        _build_device = self.device
+        _issuer.build_device = self.device
         dev_model = model
         assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
         # hand-written HIP kernels on the GPU 16-bit paths (bf16, or fp16 = the reference's apex-O2 arithmetic)
@@ -315,7 +321,7 @@ class InferenceEngine:
                 b = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
             self.heads_w = w.contiguous(memory_format=torch.channels_last)
             self.heads_b = b.contiguous()
-        _build_device = None
+        _issuer.build_device = None
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -323,8 +329,7 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
-        global _engine
-        _engine = self._id
+        _issuer.engine = self._id
         if self.stem_w is not None:   # fused stem: fp32 NCHW images -> conv 7x7 s2 + BN + ReLU -> bf16 NHWC
             lib = _lib.load()
             images = images.float().contiguous()
