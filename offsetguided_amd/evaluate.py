@@ -133,7 +133,16 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
         for image_poses, image_meta in zip(poses.result(), metas):   # zip drops the padded images of a ragged batch
             poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids)
 
+    preprocess = None
     for batch_idx, (images, _, metas) in enumerate(data_loader):
+        if isinstance(images, (list, tuple)):
+            # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
+            # (RescaleLongAbsolute + CenterPad + ToTensor + Normalize, pinned double-buffered H2D); metas are derived here
+            if preprocess is None:
+                from .transforms import EvalPreprocess
+                preprocess = EvalPreprocess(args.long_edge, device=dev, fixed_height=args.fixed_height)
+            assert not args.fixed_height, 'RescaleHighAbsolute + RightDownPad (--fixed-height) is not built on the device'
+            images, metas = preprocess(list(images), image_ids=[m['image_id'] for m in metas])
         images = feeder(images)
         full_batch = full_batch or images.shape[0]
         if images.shape[0] < full_batch:   # last batch of the dataset: fill up to the engine's batch, results are dropped

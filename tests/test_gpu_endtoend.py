@@ -209,6 +209,53 @@ def test_run_images_values(dev, stage, monkeypatch):
     assert n_real > 0, 'the default-init model should yield pseudo-poses above the thresholds'
 
 
+def test_run_images_from_raw_uint8_images(dev, monkeypatch):
+    """The harness fed with raw uint8 images of mixed sizes: the device input chain (EvalPreprocess) supplies the network
+    input and the metas; results map back to ORIGINAL image coordinates through annotations_inverse."""
+    from offsetguided_amd import evaluate, transforms
+    torch.manual_seed(0)
+    a = evaluate.evaluate_cli(['--no-pretrain', '--initialize-whole', 'False', '--topk', '32', '--thre-hmp', '0.04',
+                               '--person-thre', '0.04', '--dist-max', '40', '--long-edge', '256', '--batch-size', '2',
+                               '--print-freq', '1'])
+    model, _ = models.model_factory(a)
+    rng = np.random.default_rng(5)
+    sizes = [(120, 200), (333, 250), (256, 256), (90, 64)]
+    raw = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    loader = [(raw[0:2], [None] * 2, [{'image_id': 1}, {'image_id': 2}]), (raw[2:4], [None] * 2, [{'image_id': 3}, {'image_id': 4}])]
+    seen = []
+    build = decoder.decoder_factory
+
+    def recording_factory(args):
+        proc = build(args)
+        submit = proc.submit
+
+        def spy(features, **kw):
+            seen.append((features[0][0][-1].cpu().numpy().copy(), features[1][0][-1].cpu().numpy().copy()))
+            return submit(features, **kw)
+        proc.submit = spy
+        return proc
+    monkeypatch.setattr(decoder, 'decoder_factory', recording_factory)
+    results, ids = evaluate.run_images(a, data_loader=loader, model=model)
+    assert ids == [1, 2, 3, 4]
+    pre = transforms.EvalPreprocess(256)
+    exp_results, exp_ids = [], []
+    for (hm, off), (imgs, _, metas) in zip(seen, loader):
+        _, pmetas = pre(list(imgs), image_ids=[m['image_id'] for m in metas])
+        poses, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, **OFLAGS)
+        for image_poses, meta in zip(poses, pmetas):
+            evaluate.poses_to_results(image_poses, meta, exp_results, exp_ids)
+    assert exp_ids == ids and len(results) == len(exp_results)
+    for got, exp in zip(results, exp_results):
+        assert got['image_id'] == exp['image_id'] and got['keypoints'] == exp['keypoints'] and abs(got['score'] - exp['score']) <= 1e-6
+    # coordinates are in ORIGINAL image pixels: a detection at the centre of the 256x256 network input maps to the centre of
+    # the original image (the pseudo-poses of a random network may also sit in the padding, so no frame check here)
+    _, pmetas = pre([raw[1]], image_ids=[2])
+    centre = np.zeros((1, 17, 6), np.float32)
+    centre[0, :, 0], centre[0, :, 1] = 127.5, 127.5
+    back = evaluate.annotations_inverse(centre, pmetas[0])
+    assert abs(back[0, 0, 0] - (250 - 1) / 2) < 1.0 and abs(back[0, 0, 1] - (333 - 1) / 2) < 1.0
+
+
 # ---------------------------------------------------------------------------------- precision statement
 def _pose_keypoints(poses):
     """{global_idx: score} over the keypoints of all poses of one image."""
