@@ -91,6 +91,30 @@ __device__ __forceinline__ void limb_rows(const Args &a, int n, int l, int lane,
     const int cf = a.jf[l], ct = a.jt[l];
     const long HW = (long)H * W;
 
+    // The offset gather of the lane's FIRST from-candidate (two dependent round trips: candidate index, then the offset
+    // taps in a tensor that is cold by now) is issued before the to-candidates are staged, so the two latencies overlap.
+    auto gather_offsets = [&](int64_t id, int yi, int xi, float (&o4)[ND]) {   // offset at the ORIGINAL flat index (collect.py:143-147)
+        if (off_lowres) {
+            const int h4 = H / 4, w4 = W / 4;
+            const float *px = offs + ((size_t)n * ND * L + ND * l) * h4 * w4;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) o4[c] = bilinear4_at(px + (size_t)c * h4 * w4, h4, w4, yi, xi);
+        } else {
+            const float *px = offs + ((size_t)n * ND * L + ND * l) * HW;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) o4[c] = px[(size_t)c * HW + id];
+        }
+    };
+    int64_t id_first = 0;
+    float s_first = 0.f, o_first[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) o_first[c] = 0.f;
+    if (lane < K) {
+        id_first = (int64_t)idf[lane];
+        s_first = sf[lane];
+        gather_offsets(id_first, (int)((unsigned)id_first / (unsigned)W), (int)((unsigned)id_first % (unsigned)W), o_first);
+    }
+
     for (int m = lane; m < Kp; m += GROUP) {
         if (m < K) {
             const int id = (int)idt[m];   // flat indices fit 31 bits (checked by the entry points): 32-bit divisions
@@ -109,22 +133,19 @@ __device__ __forceinline__ void limb_rows(const Args &a, int n, int l, int lane,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     for (int k = lane; k < K; k += GROUP) {
-        const int64_t id = (int64_t)idf[k];
+        const bool first = k == lane;
+        const int64_t id = first ? id_first : (int64_t)idf[k];
         const int xi = (int)((unsigned)id % (unsigned)W), yi = (int)((unsigned)id / (unsigned)W);
-        const float s1 = sf[k];
+        const float s1 = first ? s_first : sf[k];
         int xs = xi, ys = yi;
         if (s1 < thre) { xs -= 100000; ys -= 100000; }
         const float xf = (float)xs, yf = (float)ys;
-        float o4[ND];  // offset at the ORIGINAL flat index (collect.py:143-147)
-        if (off_lowres) {
-            const int h4 = H / 4, w4 = W / 4;
-            const float *px = offs + ((size_t)n * ND * L + ND * l) * h4 * w4;
+        float o4[ND];
+        if (first) {
 #pragma unroll
-            for (int c = 0; c < ND; ++c) o4[c] = bilinear4_at(px + (size_t)c * h4 * w4, h4, w4, yi, xi);
+            for (int c = 0; c < ND; ++c) o4[c] = o_first[c];
         } else {
-            const float *px = offs + ((size_t)n * ND * L + ND * l) * HW;
-#pragma unroll
-            for (int c = 0; c < ND; ++c) o4[c] = px[(size_t)c * HW + id];
+            gather_offsets(id, yi, xi, o4);
         }
 #ifdef OG_COLLECT_STAMP
         OG_COLLECT_STAMP(12, o4[0]);
