@@ -53,7 +53,11 @@ namespace {
 #ifndef OG_K1_LOAD_AUX
 #define OG_K1_LOAD_AUX 2  // nt: the heatmap is streamed once (+8% read bandwidth measured on MI355X)
 #endif
-constexpr int kPrefetch = 4;      // rows in flight per lane
+#ifndef OG_K1_BAND_PF
+#define OG_K1_BAND_PF 3
+#endif
+constexpr int kPrefetch = OG_K1_BAND_PF;      // rows in flight per lane: 3 (2 .. 3 measured best on MI355X: 56.7 us for the three launches, 4: 60.4,
+                                              // 6 / 8: 63.2, 1: 68; deeper queues lose -- more DRAM rows open at once, not occupancy)
 constexpr int kInterior = 62;     // interior lanes per wave panel
 constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
 constexpr uint32_t kLaneOob = 0x80000000u;  // offset of lanes outside the image
@@ -791,7 +795,7 @@ OG_API int og_hmp_nms_f32(const float *heat, long planes, int H, int W, float *o
 namespace {
 
 #ifndef OG_K1_SINGLE_PF
-#define OG_K1_SINGLE_PF 8
+#define OG_K1_SINGLE_PF 3
 #endif
 constexpr int kSinglePF = OG_K1_SINGLE_PF;   // rows in flight per streaming wave
 
