@@ -210,12 +210,13 @@ int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int targe
  * oracle/og_oracle.c:ogo_resize_cubic_u8 -- parity with cv2 itself is unpinned (third-party, absent from the build). */
 int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int new_h, int new_w, void *stream);
 
-/* The whole input chain of evaluate.py:157-168 in one pass: rescale to (new_h,new_w) as above, CenterPad to
- * (target_h,target_w) with the fill colour, ToTensor, Normalize -> out fp32 (3,target_h,target_w); ltrb as
- * og_center_pad_normalize_u8.  The resized uint8 image is never stored. */
+/* The whole input chain of evaluate.py:150-168 in one pass: rescale to (new_h,new_w) as above, pad to (target_h,target_w)
+ * with the fill colour -- corner_pad 0: CenterPad (transforms/pad.py:35-62, the --long-edge chain), 1: RightDownPad
+ * (transforms/pad.py:70-118, the --fixed-height chain: left = top = 0) --, ToTensor, Normalize -> out fp32
+ * (3,target_h,target_w); ltrb as og_center_pad_normalize_u8.  The resized uint8 image is never stored. */
 int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, int new_h, int new_w, int target_h, int target_w,
-                                const float *mean3, const float *std3, const float *fill3, float *out, int *ltrb,
-                                void *stream);
+                                int corner_pad, const float *mean3, const float *std3, const float *fill3, float *out,
+                                int *ltrb, void *stream);
 
 /* ---- network stem: convolution(7, 3, 128, stride=2) + BN + ReLU  models/hourglass_104.py:283, :16-30 ----
  * images (N,3,H,W) fp32 (H, W multiples of 32) -> out (N,H/2,W/2,128) bf16 NHWC, input conversion and epilogue fused.

@@ -113,15 +113,16 @@ OG_API int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned c
 }
 
 OG_API int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, int new_h, int new_w, int target_h, int target_w,
-                                       const float *mean3, const float *std3, const float *fill3, float *out, int *ltrb,
-                                       void *stream)
+                                       int corner_pad, const float *mean3, const float *std3, const float *fill3, float *out,
+                                       int *ltrb, void *stream)
 {
     const char *name = "og_rescale_pad_normalize_u8";
     OG_REQUIRE(img && mean3 && std3 && fill3 && out, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(h > 0 && w > 0 && new_h > 0 && new_w > 0 && (long)h * w < (1l << 28), OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE(target_h >= new_h && target_w >= new_w, OG_EINVAL, "%s: the rescaled image must fit the target", name);
-    // transforms/pad.py:43-55: left = int((T - w) / 2.0), top likewise; the rest goes right / down
-    const int left = (int)((target_w - new_w) / 2.0), top = (int)((target_h - new_h) / 2.0);
+    // CenterPad (transforms/pad.py:43-55): left = int((T - w) / 2.0), top likewise, the rest goes right / down;
+    // RightDownPad (transforms/pad.py:95-118, the --fixed-height chain of evaluate.py:150-156): everything goes right / down
+    const int left = corner_pad ? 0 : (int)((target_w - new_w) / 2.0), top = corner_pad ? 0 : (int)((target_h - new_h) / 2.0);
     if (ltrb) { ltrb[0] = left; ltrb[1] = top; ltrb[2] = target_w - new_w - left; ltrb[3] = target_h - new_h - top; }
     PrepArgs a;
     for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; a.fill[c] = fill3[c]; }

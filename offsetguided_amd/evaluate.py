@@ -137,11 +137,11 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
     for batch_idx, (images, _, metas) in enumerate(data_loader):
         if isinstance(images, (list, tuple)):
             # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
-            # (RescaleLongAbsolute + CenterPad + ToTensor + Normalize, pinned double-buffered H2D); metas are derived here
+            # (RescaleLongAbsolute + CenterPad, or with --fixed-height RescaleHighAbsolute + RightDownPad of :150-156, then
+            # ToTensor + Normalize; pinned double-buffered H2D); metas are derived here
             if preprocess is None:
                 from .transforms import EvalPreprocess
                 preprocess = EvalPreprocess(args.long_edge, device=dev, fixed_height=args.fixed_height)
-            assert not args.fixed_height, 'RescaleHighAbsolute + RightDownPad (--fixed-height) is not built on the device'
             images, metas = preprocess(list(images), image_ids=[m['image_id'] for m in metas])
         images = feeder(images)
         full_batch = full_batch or images.shape[0]

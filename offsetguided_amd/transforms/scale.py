@@ -70,8 +70,10 @@ class EvalPreprocess:
     `annotations_inverse` needs (offset, scale) after rescale + centre pad.  Host images are staged through two pinned
     buffers and copied asynchronously; batch i+1 can be prepared while batch i is in the network."""
 
-    def __init__(self, long_edge, device='cuda:0', mean=data_mean, std=data_std, fill=FILL, fixed_height=False):
-        self.long_edge, self.device, self.fixed_height = long_edge, torch.device(device), fixed_height
+    def __init__(self, long_edge, device='cuda:0', mean=data_mean, std=data_std, fill=FILL, fixed_height=False, max_stride=128):
+        """fixed_height: RescaleHighAbsolute(long_edge) + RightDownPad(max_stride) (evaluate.py:150-156) instead of
+        RescaleLongAbsolute + CenterPad: every image of a batch must then give the same padded size."""
+        self.long_edge, self.device, self.fixed_height, self.max_stride = long_edge, torch.device(device), fixed_height, max_stride
         f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
         self._mean, self._std, self._fill = f3(mean), f3(std), f3(fill)
         self._stage, self._turn = [None, None], 0
@@ -105,17 +107,26 @@ class EvalPreprocess:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(self.copy_stream)
         dev_raw.record_stream(cur)
-        out = torch.empty((len(images), 3, T, T), dtype=torch.float32, device=self.device)
+        targets = [rescale_size(w, h, T, self.fixed_height) for h, w in sizes]
+        if self.fixed_height:   # RightDownPad: up to the next multiple of max_stride (transforms/pad.py:100-103)
+            up = lambda v: (v + self.max_stride - 1) // self.max_stride * self.max_stride  # noqa: E731
+            padded = {(up(th), up(tw)) for tw, th in targets}
+            assert len(padded) == 1, f'--fixed-height: the images of one batch pad to different sizes {sorted(padded)}'
+            PH, PW = padded.pop()
+        else:
+            PH = PW = T
+        out = torch.empty((len(images), 3, PH, PW), dtype=torch.float32, device=self.device)
         metas, o = [], 0
         for i, (h, w) in enumerate(sizes):
-            tw, th = rescale_size(w, h, T, self.fixed_height)
+            tw, th = targets[i]
             ltrb = (C.c_int * 4)()
-            _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, T, T, self._mean, self._std,
-                                                       self._fill, _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
+            _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, PH, PW,
+                                                       int(self.fixed_height), self._mean, self._std, self._fill,
+                                                       _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
             o += h * w * 3
             meta, _ = rescale_meta(initial_meta(w, h, None if image_ids is None else image_ids[i]), None, w, h, tw, th)
             meta['offset'] = meta['offset'] - np.array(ltrb[:2], np.float64)          # CenterPad, transforms/pad.py:28-31
             meta['valid_area'][:2] += np.array(ltrb[:2], np.float64)
-            meta['width_height'] = np.array([T, T])
+            meta['width_height'] = np.array([PW, PH])
             metas.append(meta)
         return out, metas

@@ -105,6 +105,17 @@ def test_resize_and_fused_chain_bit_exact_vs_restatement():
         sx, sy = (tw - 1) / (w - 1), (th - 1) / (h - 1)
         assert np.allclose(metas[0]['scale'], [sx, sy]) and np.allclose(metas[0]['offset'], [-left, -top])
         assert metas[0]['image_id'] == 5
+    # --fixed-height chain: RescaleHighAbsolute + RightDownPad to a multiple of 128, image in the top-left corner
+    im = images[2]                                               # 375 x 500 -> 640 x 853 -> padded 640 x 896
+    out, metas = transforms.EvalPreprocess(640, fixed_height=True)([im])
+    assert transforms.rescale_size(500, 375, 640, fixed_height=True) == (853, 640) and out.shape == (1, 3, 640, 896)
+    canvas = np.empty((640, 896, 3), np.uint8)
+    canvas[:] = np.array(transforms.pad.FILL, np.uint8)
+    canvas[:640, :853] = oracle.resize_cubic_u8(im, 640, 853)
+    assert torch.equal(out[0].cpu(), (torch.from_numpy(canvas).permute(2, 0, 1).float().div(255) - mean) / std)
+    assert np.allclose(metas[0]['offset'], [0, 0]) and tuple(metas[0]['width_height']) == (896, 640)
+    with pytest.raises(AssertionError):
+        transforms.EvalPreprocess(640, fixed_height=True)([images[2], images[0]])   # different padded widths in one batch
     pre = transforms.EvalPreprocess(640)
     for _ in range(3):                                           # a batch of mixed sizes, staging buffers reused
         out, metas = pre(images[:4])
