@@ -127,11 +127,13 @@ int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const fl
 /* ---- a8+a9+a10 in ONE call: LimbsCollect.generate_limbs  decoder/collect.py:62-236 on (N,C,H,W) hi-res heatmaps ----
  * = og_nms_topk_f32 (joint_dets, decoder/heatmap.py:52-59) followed by og_collect_limbs_full_f32, same arguments and
  * bit-identical limbs.  topk_scores / topk_inds: optional (N,C,k) outputs of the joint_dets stage (both or neither).
- * flags 0: three launches (band top-k, merge, pairing) queued back to back -- the measured-fastest form on MI355X.
+ * flags 0: two launches queued back to back -- band top-k, then ONE kernel that merges the band lists and pairs the limbs
+ *   (workgroup (image, limb type) merges its two joint planes in LDS and pairs from there; the (N,C,k) lists are written by
+ *   extra workgroups of the same launch) -- the measured-fastest form on MI355X.
  * flags OG_LIMBS_SINGLE_LAUNCH: one persistent kernel -- one workgroup per CU streams a feedback-balanced share of the
  *   planes' rows (one HBM read of the heatmaps), the last workgroup to finish an image merges its candidate lists and
  *   writes the limb rows.  Shapes it does not take (W % 4 != 0, k > 64, planes much smaller than a workgroup's share of
- *   rows) silently run as the three launches.  Measured slower than flags 0 at bs8 640x640, kept
+ *   rows) silently run as flags 0.  Measured slower than flags 0 at bs8 640x640, kept
  *   as the basis of the next step.
  * workspace: og_generate_limbs_workspace_bytes(N, C, H, W, k), 16-byte aligned, ZERO-FILLED ONCE by the caller
  * (hipMemset) before its first use; every call leaves it ready for the next one (any shape, any flags).  Its first

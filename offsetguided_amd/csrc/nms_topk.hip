@@ -554,67 +554,50 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 //   B) compact the keys >= L (usually just over k of them);
 //   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
-template <bool NMS_MODE, bool FUSED = false>
-__global__ void __launch_bounds__(256)
-merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
-                   int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
-                   const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
-                   float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
+// One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
+// this the same number of times: it contains workgroup barriers).  `all` / `flt`: n_all = nbands * k keys each, in LDS;
+// `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
+template <bool NMS_MODE, bool FUSED, class Emit>
+__device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, const int *__restrict__ gc, uint64_t *all,
+                                            uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
+                                            const float *__restrict__ p, int H, int W, int k, int nbands, int t_sub, Emit &&emit)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const int plane = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n_all = nbands * k;
-    uint64_t *all = lds64;             // n_all keys (0 = empty slot)
-    uint64_t *flt = lds64 + n_all;     // subset, then filtered keys
-    __shared__ uint64_t s_bound;
-    __shared__ int s_nf;
-    const uint64_t *gk = band_keys + (size_t)plane * n_all;
-    const int *gc = band_cnt + (size_t)plane * nbands;
-    float *os = out_scores + (size_t)plane * k;
-    int64_t *oi = out_inds + (size_t)plane * k;
-
+    const int n_all = nbands * k, lane = tid & 63;
     // keys and band counts are fetched together (one memory round trip), masked afterwards
-    for (int i = tid; i < n_all; i += blockDim.x) {
+    for (int i = tid; i < n_all; i += nthr) {
         const uint64_t key = gk[i];
         const int c = gc[i / k];
         all[i] = (i % k < c) ? key : 0ull;
     }
-    if (tid == 0) { s_bound = 0ull; s_nf = 0; }
-    if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
-        for (int i = tid; i < nbands; i += blockDim.x) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
-    if (blockIdx.x == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
+    if (tid == 0) { *s_bound = 0ull; *s_nf = 0; }
     __syncthreads();
     // A) k-th largest of the subset {first t_sub keys of each band}
     const int n_sub = nbands * t_sub;
-    for (int i = tid; i < n_sub; i += blockDim.x) flt[i] = all[(i / t_sub) * k + i % t_sub];
+    for (int i = tid; i < n_sub; i += nthr) flt[i] = all[(i / t_sub) * k + i % t_sub];
     __syncthreads();
-    for (int i = tid; i < n_sub; i += blockDim.x) {
+    for (int i = tid; i < n_sub; i += nthr) {
         const uint64_t mine = flt[i];
-        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) s_bound = mine;
+        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) *s_bound = mine;
     }
     __syncthreads();
-    const uint64_t bound = s_bound;
+    const uint64_t bound = *s_bound;
     // B) keys >= bound (order does not matter: ranks are recomputed)
-    for (int i = tid; i < n_all; i += blockDim.x) {
+    for (int i = tid; i < n_all; i += nthr) {
         const uint64_t key = all[i];
-        if (key != 0ull && key >= bound) flt[atomicAdd(&s_nf, 1)] = key;
+        if (key != 0ull && key >= bound) flt[atomicAdd(s_nf, 1)] = key;
     }
     __syncthreads();
-    const int nf = s_nf;
+    const int nf = *s_nf;
     // C) rank and emit
-    for (int i = tid; i < nf; i += blockDim.x) {
+    for (int i = tid; i < nf; i += nthr) {
         const uint64_t mine = flt[i];
         const int rank = og_count_greater(flt, nf, mine);
-        if (rank < k) {
-            os[rank] = og_key_value(mine);
-            oi[rank] = (int64_t)og_key_index(mine);
-        }
+        if (rank < k) emit(rank, og_key_value(mine), (long)og_key_index(mine));
     }
     int t = min(nf, k);
     if (NMS_MODE && t < k && tid < 64) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
-        const float *p = in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W);
         auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
         const long hw = (long)H * W;
         for (long base = 0; base < hw && t < k; base += 64) {
@@ -633,13 +616,89 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
             }
             const uint64_t mask = __builtin_amdgcn_ballot_w64(zero);
             const int slot = t + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (zero && slot < k) {
-                os[slot] = 0.f;
-                oi[slot] = i;
-            }
+            if (zero && slot < k) emit(slot, 0.f, i);
             t += __builtin_popcountll(mask);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// merge kernel: one workgroup per plane selects the plane's top-k from the sorted band lists.
+//   A) a lower bound L on the k-th best: the k-th largest among the first `t` keys of every
+//      band (a subset of all keys, so the true k-th best is >= L);
+//   B) compact the keys >= L (usually just over k of them);
+//   C) rank them by counting and write the k best in order.
+// ---------------------------------------------------------------------------------------
+template <bool NMS_MODE, bool FUSED = false>
+__global__ void __launch_bounds__(256)
+merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
+                   int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
+                   const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
+                   float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const int plane = blockIdx.x, tid = threadIdx.x;
+    const int n_all = nbands * k;
+    __shared__ uint64_t s_bound;
+    __shared__ int s_nf;
+    float *os = out_scores + (size_t)plane * k;
+    int64_t *oi = out_inds + (size_t)plane * k;
+    if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
+        for (int i = tid; i < nbands; i += blockDim.x) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
+    if (blockIdx.x == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
+    merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, lds64, lds64 + n_all,
+                                 &s_bound, &s_nf, tid, 256,
+                                 in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W), H, W, k, nbands,
+                                 t_sub, [&](int rank, float v, long idx) { os[rank] = v; oi[rank] = (int64_t)idx; });
+}
+
+// Merge + K2 in one launch (the tail of og_generate_limbs_f32): workgroup (image, limb type) merges the limb's two joint
+// planes itself -- 256 threads per plane, both lists stay in LDS -- and its first wave pairs the candidates straight from
+// there (collect_body.h); behind them ceil(planes / 2) workgroups write the (N,C,k) lists the caller sees and clean the
+// workspace.  A plane is merged by every limb that uses it (2.2 times on the COCO skeleton): 4 KB of L2 reads each, against
+// a launch, a launch gap and a round trip of the lists through memory.
+template <int ND>
+__global__ void __launch_bounds__(512)
+merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt, int *__restrict__ hist_all,
+                     uint64_t *__restrict__ ws_magic, uint64_t magic, const float *__restrict__ in, int planes, int nbands,
+                     int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    __shared__ uint64_t s_bound[2];
+    __shared__ int s_nf[2];
+    const int k = a.K, H = a.H, W = a.W, n_all = nbands * k, Kp = (k + 3) & ~3;
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    uint64_t *all = lds64 + (size_t)half * 2 * n_all, *flt = all + n_all;
+    float *ls = reinterpret_cast<float *>(lds64 + 4 * (size_t)n_all);   // [2][Kp] scores | [2][Kp] indices | pairing scratch
+    int *li = reinterpret_cast<int *>(ls + 2 * Kp);
+    float *sm = ls + 4 * Kp;
+    const bool limb = (int)blockIdx.x < NL;
+    int plane, n = 0, l = 0;
+    bool live = true;
+    if (limb) {
+        n = blockIdx.x / a.L;
+        l = blockIdx.x % a.L;
+        plane = n * a.C + (half ? a.jt[l] : a.jf[l]);
+    } else {
+        plane = 2 * ((int)blockIdx.x - NL) + half;
+        live = plane < planes;
+        plane = live ? plane : planes - 1;   // the odd plane out: merged twice, written once
+        if (live && hist_all)
+            for (int i = tid; i < nbands; i += 256) hist_all[(size_t)plane * nbands + i] = 0;
+        if (plane == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
+    }
+    float *os = limb ? ls + half * Kp : out_scores + (size_t)plane * k;
+    int *oi32 = li + half * Kp;
+    int64_t *oi64 = out_inds + (size_t)plane * k;
+    merge_plane<true, false>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, all, flt, &s_bound[half],
+                             &s_nf[half], tid, 256, in + (size_t)plane * H * W, H, W, k, nbands, t_sub,
+                             [&](int rank, float v, long idx) {
+                                 if (limb) { os[rank] = v; oi32[rank] = (int)idx; }
+                                 else if (live) { os[rank] = v; oi64[rank] = (int64_t)idx; }
+                             });
+    if (!limb) return;
+    __syncthreads();
+    if (threadIdx.x < 64) og_collect::limb_rows<ND, int>(a, n, l, threadIdx.x, ls, li, ls + Kp, li + Kp, sm);
 }
 
 struct Plan {
@@ -683,9 +742,14 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     return true;
 }
 
+struct Pairing {   // og_generate_limbs_f32: the merge launch also pairs the limbs
+    og_collect::Args a;
+    int nd, N;
+};
+
 template <bool NMS_MODE, bool FUSED = false>
 int run_topk(const float *in, long planes, int H, int W, int k, float *out_scores, int64_t *out_inds,
-             void *workspace, size_t workspace_bytes, hipStream_t stream, const char *name)
+             void *workspace, size_t workspace_bytes, hipStream_t stream, const char *name, const Pairing *pair = nullptr)
 {
     OG_REQUIRE(in && out_scores && out_inds && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(planes > 0 && H > 0 && W > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
@@ -728,6 +792,17 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
+    if constexpr (NMS_MODE && !FUSED) {
+        const size_t plds = 2 * mlds + (size_t)((k + 3) & ~3) * 32;
+        if (pair && plds <= 64 * 1024) {
+            const int NL = pair->N * pair->a.L;
+            auto kern = pair->nd == 2 ? merge_collect_kernel<2> : merge_collect_kernel<4>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, cnts, hist, magic,
+                               p.magic, in, (int)planes, p.nbands, p.t_sub, out_scores, out_inds, pair->a, NL);
+            OG_LAUNCH_CHECK(name);
+            return 1;   // paired
+        }
+    }
     hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
                        magic, p.magic, in, H, W, k, p.nbands, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
@@ -844,7 +919,7 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
     P2Plan p;
     const bool single = (flags & OG_LIMBS_SINGLE_LAUNCH) != 0 && (uintptr_t)hmps_hr % 16 == 0 &&
                         make_plan2((long)N * C, H, W, k, C, device_cu_count(), &p);
-    if (!single) {  // shapes the persistent kernel does not take: the three-launch form
+    if (!single) {  // the default, and shapes the persistent kernel does not take: band top-k, then merge + pairing
         const bool own_lists = topk_scores == nullptr;
         const size_t need = two_step_bytes(N, C, H, W, k, own_lists);
         OG_REQUIRE(need != 0, OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d", name, W, k);
@@ -854,8 +929,13 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
         const size_t topk = og_align_up(og_topk_workspace_bytes((long)N * C, H, W, k), 256);
         float *sc = own_lists ? reinterpret_cast<float *>(ws2 + topk + (size_t)N * C * k * 8) : topk_scores;
         int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
-        const int rc = og_nms_topk_f32(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, stream);
-        if (rc != OG_OK) return rc;
+        // two launches: the merge launch pairs the limbs as well (OG_K1_PAIR_IN_MERGE=0: merge, then the collect kernel)
+        static const int pair_in_merge = env_int("OG_K1_PAIR_IN_MERGE", 1);
+        const Pairing pr{ca, vector_nd, N};
+        const bool can_pair = pair_in_merge && (long)H * W < (1l << 31) && k <= 2048;
+        const int rc = run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
+                                      can_pair ? &pr : nullptr);
+        if (rc < 0 || rc == 1) return rc < 0 ? rc : OG_OK;
         return og_collect_limbs_full_f32(sc, id, offs, off_is_lowres, vector_nd, scales, scales_mode, jitter, jitter_mode, N, C,
                                          H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs, stream);
     }

@@ -21,7 +21,7 @@ class LimbsCollect(object):
     K2 samples the stride-4 maps at the peaks with the arithmetic of F.interpolate(x4).
 
     On hi-res heatmaps the whole of generate_limbs -- NMS, top-k and the pairing -- is ONE C call
-    (og_generate_limbs_f32): three launches queued back to back, or with `single_launch = True` (OG_K1_SINGLE=1) one
+    (og_generate_limbs_f32): two launches queued back to back (band top-k; merge + pairing), or with `single_launch = True` (OG_K1_SINGLE=1) one
     persistent kernel with identical results (measured slower on MI355X).
     """
 

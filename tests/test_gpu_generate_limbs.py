@@ -1,5 +1,5 @@
 """og_generate_limbs_f32 -- joint_dets + limb pairing in ONE call (decoder/heatmap.py:15-59 + decoder/collect.py:62-236),
-both as the persistent single-launch kernel (OG_LIMBS_SINGLE_LAUNCH) and as three queued launches (flags 0) -- through the
+both as the persistent single-launch kernel (OG_LIMBS_SINGLE_LAUNCH) and as two queued launches (flags 0: band top-k, merge + pairing) -- through the
 C ABI, against the oracle and against the separate entry points (og_nms_topk_f32 + og_collect_limbs_full_f32).
 
 Bit-exact candidate lists (scores, flat indices) and limb rows; the limb score within 1e-4 of the oracle (the device exp()).
@@ -82,7 +82,7 @@ def test_single_launch_matches_oracle_and_three_launch(dev, n, size, k):
     assert torch.equal(l3, limbs) and torch.equal(s3, sc) and torch.equal(i3, ix)      # same code, same bits
     l_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False)             # lists optional
     assert torch.equal(l_only, limbs)
-    l0, s0, i0, _ = run_single(t_hr, t_off, k, dev, single=False)                   # flags 0: three launches behind one call
+    l0, s0, i0, _ = run_single(t_hr, t_off, k, dev, single=False)                   # flags 0: band top-k + merge-and-pair kernel behind one call
     assert torch.equal(l0, limbs) and torch.equal(s0, sc) and torch.equal(i0, ix)
     l0_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False, single=False)
     assert torch.equal(l0_only, limbs)

@@ -74,6 +74,15 @@ def main():
                                                  _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs1),
                                                  1, _lib.ptr(ws1), ws1.numel(), sp), lib)
 
+        limbs2 = torch.empty((n, L, k, 13), device=dev)
+        sc2 = torch.empty((n, c, k), device=dev)
+        ix2 = torch.empty((n, c, k), dtype=torch.int64, device=dev)
+
+        def two(i):   # the default form: band kernel + merge-and-pair kernel
+            _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[i % a.rotate]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
+                                                 _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
+                                                 _lib.ptr(limbs2), 0, _lib.ptr(ws1), ws1.numel(), sp), lib)
+
         def three(i):
             _lib.check(lib.og_nms_topk_f32(_lib.ptr(hrs[i % a.rotate]), n * c, h, w, k, _lib.ptr(sc), _lib.ptr(ix), _lib.ptr(ws3),
                                            ws3.numel(), sp), lib)
@@ -84,8 +93,9 @@ def main():
         for i in range(a.rotate):
             single(i)
             three(i)
+            two(i)
             torch.cuda.synchronize()
-            ok = ok and torch.equal(limbs1, limbs3)
+            ok = ok and torch.equal(limbs1, limbs3) and torch.equal(limbs2, limbs3) and torch.equal(sc2, sc) and torch.equal(ix2, ix)
         tick = int(ws1[:61440].view(torch.int32).abs().sum())
 
         def timed(fn, pre=None):
@@ -107,8 +117,8 @@ def main():
             t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
             return float(np.median(t)), float(t.min())
 
-        res = {'single cold': timed(single), 'three cold': timed(three),
-               'single after K1a': timed(single, k1a), 'three after K1a': timed(three, k1a)}
+        res = {'single cold': timed(single), 'two cold': timed(two), 'three cold': timed(three),
+               'single after K1a': timed(single, k1a), 'two after K1a': timed(two, k1a), 'three after K1a': timed(three, k1a)}
         if a.burst:
             ga = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
             gb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
@@ -126,10 +136,11 @@ def main():
                     ga @ gb
                 k1a(i)
             res[f'single after {a.burst} ms of GEMM + K1a'] = timed(single, burst_then_k1a)
+            res[f'two after {a.burst} ms of GEMM + K1a'] = timed(two, burst_then_k1a)
             res[f'three after {a.burst} ms of GEMM + K1a'] = timed(three, burst_then_k1a)
         st = ws1[61440:65536].view(torch.int32).cpu().numpy()
         rows = np.diff(st[16:16 + 257])
-        print(f'== {tag}: single == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
+        print(f'== {tag}: single == two == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
         for name, (med, mn) in res.items():
             print(f'   {name:36s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
         sys.stdout.flush()
