@@ -63,6 +63,7 @@ struct ConvArgs {
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
     int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
     int store_policy;            // halo kernel's output stores: 0 plain, 1 sc1 (write-through), 2 nt (OG_CONV_STORE)
+    int items;                   // halo kernel: work items (pixel tile x cout tile) per workgroup (OG_CONV_HALO_ITEMS)
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
 };
 
@@ -465,41 +466,63 @@ conv3x3_halo_kernel(ConvArgs a)
     unsigned char *const bufA = lds, *const bufB = lds + 2 * kABytes;  // [A0 | A1 | B0..B3]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    CONV_STAMP(0);
-    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    const int n_tile = blockIdx.x % a.n_tiles;
-    int t = blockIdx.x / a.n_tiles;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, img = t / tiles_y;
-    const int n0 = n_tile * BN, chunks = a.Cin >> 6;
+    // A workgroup takes a.items consecutive work items (item = pixel tile x 128-cout tile, cout tile fastest: the items of
+    // one workgroup share their halo); the first halo chunk and the first three weight tiles of item i+1 are fetched
+    // during the last chunk of item i, so only the first item of a workgroup pays the 6-9 us wait for its first data
+    // (with one workgroup per CU -- the kernel owns all of its LDS -- nothing else could run in that gap).
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH, chunks = a.Cin >> 6;
+    const int n_items = a.N * tiles_y * tiles_x * a.n_tiles;
+    int item = blockIdx.x * a.items;
+    const int item_end = min(item + a.items, n_items);
+#define HALO_STAMP(i)                                                                                              \
+    do {                                                                                                            \
+        if (a.stamps && tid == 0) a.stamps[(size_t)item * 8 + (i)] = __builtin_amdgcn_s_memrealtime();              \
+    } while (0)
+#define HALO_CLOCK(i)                                                                                              \
+    do {                                                                                                            \
+        if (a.stamps && tid == 0) a.stamps[(size_t)item * 8 + (i)] = __builtin_readcyclecounter();                  \
+    } while (0)
+    HALO_STAMP(0);
 
     // ---- loaders: byte offsets into x / w for buffer-addressed LDS-DMA; out-of-image halo pixels, the pad slot and
     // pieces past the halo get an out-of-range offset and arrive as zeros
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.w), 0, a.w_bytes, 0x00020000);
     uint32_t a_off[NPA];
+    struct Where { int n0, tx, ty, img; };
+    auto decode = [&](int it) {
+        Where wh;
+        wh.n0 = (it % a.n_tiles) * BN;
+        int t = it / a.n_tiles;
+        wh.tx = t % tiles_x;
+        t /= tiles_x;
+        wh.ty = t % tiles_y;
+        wh.img = t / tiles_y;
+        return wh;
+    };
+    auto set_a_off = [&](const Where &wh) {
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-        const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
-        const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
-        const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
-        const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        a_off[i] = ok ? (uint32_t)((((img * a.H + gy) * a.W + gx) * a.Cin + c * 8) * 2) : kOobOffset;
-    }
-    uint32_t w_off_g[PW];
+        for (int i = 0; i < NPA; ++i) {
+            const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
+            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
+            const int gy = wh.ty * TH - 1 + hy, gx = wh.tx * TW - 1 + hx;
+            const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            a_off[i] = ok ? (uint32_t)((((wh.img * a.H + gy) * a.W + gx) * a.Cin + c * 8) * 2) : kOobOffset;
+        }
+    };
+    uint32_t w_off_g[PW];   // within one 128-cout tile; the tile's base goes into the scalar offset
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = tid + 512 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_off_g[i] = (uint32_t)(((n0 + r) * 9 * a.Cin + c * 8) * 2);
+        w_off_g[i] = (uint32_t)((r * 9 * a.Cin + c * 8) * 2);
     }
     const int piece = wave * 64 * 16;
-    auto issue_a = [&](int i, int q) {  // piece i of chunk q's halo
-        blds16(xr, a_off[i], q * 128, bufA + (q & 1) * kABytes + piece + i * 8192);
+    auto issue_a = [&](int i, int q, int buf) {  // piece i of chunk q's halo
+        blds16(xr, a_off[i], q * 128, bufA + buf * kABytes + piece + i * 8192);
     };
-    auto issue_b = [&](int q, int tap, int ring) {
+    auto issue_b = [&](int w_n0, int q, int tap, int ring) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) blds16(wr, w_off_g[i], (tap * a.Cin + q * 64) * 2, bufB + ring * kBBytes + piece + i * 8192);
+        for (int i = 0; i < PW; ++i) blds16(wr, w_off_g[i], w_n0 + (tap * a.Cin + q * 64) * 2, bufB + ring * kBBytes + piece + i * 8192);
     };
 
     // ---- compute set-up
@@ -520,138 +543,234 @@ conv3x3_halo_kernel(ConvArgs a)
         const int lp = (wm * MT + m) * 16 + fcol;
         px_off[m] = ((lp / TW) * kHaloW + lp % TW) * kPitch + fk * 16;
     }
-
-    // global pixel index of this lane's pixel of column block m (epilogue + residual prefetch)
-    size_t out_px[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int lp = (wm * MT + m) * 16 + fcol;
-        out_px[m] = (size_t)(img * a.H + ty * TH + lp / TW) * a.W + tx * TW + lp % TW;
-    }
     const bool has_skip = a.skip != nullptr;
-
-    // ---- prologue: halo of chunk 0, weights of steps 0..2
+    // residual operand of this lane's accumulators (global pixel index from the tile's origin)
+    auto load_skip = [&](const Where &wh, u16x4 (&sk)[NT][MT]) {
+        // a branch, not a select on the loaded value: the select made the wave wait for the loads where they are issued
+        // (in the hand-over epilogue: behind the first half's stores, 6 us)
+        if (has_skip) {
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) issue_a(i, 0);
-    issue_b(0, 0, 0);
-    issue_b(0, 1, 1);
-    issue_b(0, 2, 2);
-    CONV_STAMP(1);
+            for (int m = 0; m < MT; ++m) {
+                const int lp = (wm * MT + m) * 16 + fcol;
+                const size_t opx = (size_t)(wh.img * a.H + wh.ty * TH + lp / TW) * a.W + wh.tx * TW + lp % TW;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    sk[n][m] = *reinterpret_cast<const u16x4 *>(a.skip + opx * a.Cout + wh.n0 + (wn * NT + n) * 16 + fk * 4);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) sk[n][m] = (u16x4){0, 0, 0, 0};
+        }
+    };
+    auto init_acc = [&](const u16x4 (&sk)[NT][MT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[n][m] = (f32x4){bf2f(sk[n][m][0]), bf2f(sk[n][m][1]), bf2f(sk[n][m][2]), bf2f(sk[n][m][3])};
+    };
+
+    // ---- prologue: halo of chunk 0, weights of steps 0..2 of the first item
+    Where cur = decode(item);
+    set_a_off(cur);
+    int w_n0 = cur.n0 * 9 * a.Cin * 2;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) issue_a(i, 0, 0);
+    issue_b(w_n0, 0, 0, 0);
+    issue_b(w_n0, 0, 1, 1);
+    issue_b(w_n0, 0, 2, 2);
+    HALO_STAMP(1);
     wait_vm_lgkm0<2 * PW>();
     // The residual operand initialises the accumulators (D = skip + sum of products) instead of being added in the
     // epilogue: its 8-B-per-lane loads are in flight while the first stages land, and the main loop carries neither
     // 32 extra registers nor extra vmcnt cases (prefetching it during the last taps stalled those steps).
     {
         u16x4 sk[NT][MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                sk[n][m] = has_skip ? *reinterpret_cast<const u16x4 *>(a.skip + out_px[m] * a.Cout + n0 + (wn * NT + n) * 16 + fk * 4)
-                                    : (u16x4){0, 0, 0, 0};
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[n][m] = (f32x4){bf2f(sk[n][m][0]), bf2f(sk[n][m][1]), bf2f(sk[n][m][2]), bf2f(sk[n][m][3])};
+        load_skip(cur, sk);
+        init_acc(sk);
     }
-    __builtin_amdgcn_s_barrier();
-    // Ping-pong: waves 4..7 (the second wave on every SIMD) run one phase behind waves 0..3, so that on each SIMD
-    // one wave is in its MFMA phase while the other fetches fragments from LDS.  They take one extra barrier here,
-    // waves 0..3 take it after the loop.
-    if (wave >= 4) __builtin_amdgcn_s_barrier();
-    CONV_STAMP(2);
 
-    // Phase R(s): counted wait, DMA issue (weights of step s+3 into the 4-ring, one halo piece of the next chunk),
-    // 16 ds_read_b128, lgkmcnt(0) | barrier | phase M(s): 32 MFMA | barrier.
-    // DMA -> ds_read ordering: a wave's pieces of B(s+1) have landed at its wait in R(s) (everything but the two
-    // youngest pieces, B(s+2)); the late group's R(s) is one barrier before the early group's R(s+1).  Ring slot of
-    // B(s+3) = slot of B(s-1), last read in R(s-1) by both groups, at least one barrier (with lgkmcnt(0)) ago.
+#ifndef OG_HALO_ABL
+#define OG_HALO_ABL 0   // timing ablations (wrong results): 1 no weight DMA, 2 no halo DMA, 4 fragments read once, 8 no MFMA
+#endif
+    bf16x8 pf[2][MT], wf[2][NT];
+    int qq = 0;   // chunks done by this workgroup: halo buffer = qq & 1, weight ring slot of a step = (qq + tap) & 3
+    for (;;) {
+        const bool has_next = item + 1 < item_end;
+        Where nxt = cur;
+        int w_n0_next = w_n0;
+        __builtin_amdgcn_s_barrier();
+        // Ping-pong: waves 4..7 (the second wave on every SIMD) run one phase behind waves 0..3, so that on each SIMD
+        // one wave is in its MFMA phase while the other fetches fragments from LDS.  They take one extra barrier here,
+        // waves 0..3 take it after the loop.
+        if (wave >= 4) __builtin_amdgcn_s_barrier();
+        HALO_STAMP(2);
+        HALO_CLOCK(6);
+
+        // Phase R(s): counted wait, DMA issue (weights of step s+3 into the 4-ring, one halo piece of the next chunk),
+        // 16 ds_read_b128, lgkmcnt(0) | barrier | phase M(s): 32 MFMA | barrier.
+        // DMA -> ds_read ordering: a wave's pieces of B(s+1) have landed at its wait in R(s) (everything but the two
+        // youngest pieces, B(s+2)); the late group's R(s) is one barrier before the early group's R(s+1).  Ring slot of
+        // B(s+3) = slot of B(s-1), last read in R(s-1) by both groups, at least one barrier (with lgkmcnt(0)) ago.
+        // The sequence runs on across the items of a workgroup: the "next chunk" of an item's last chunk is chunk 0 of
+        // the next item, B(s+3) of its last three steps are the next item's first weight tiles.
 #pragma unroll 1
-    for (int q = 0; q < chunks; ++q) {
-        const unsigned char *hA = bufA + (q & 1) * kABytes;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // B(s+2) exists unless this is one of the last two steps
-            if (tap < 7 || q + 1 < chunks) wait_vm_lgkm0<PW>();
-            else wait_vm_lgkm0<0>();
-            if (tap < NPA && q + 1 < chunks) issue_a(tap, q + 1);
-            const unsigned char *wB = bufB + ((q + tap) & 3) * kBBytes;
-            const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
-            bf16x8 pf[2][MT], wf[2][NT];
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    pf[kh][m] = *reinterpret_cast<const bf16x8 *>(hA + px_off[m] + shift + kh * 64);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    wf[kh][n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+        for (int q = 0; q < chunks; ++q, ++qq) {
+            const unsigned char *hA = bufA + (qq & 1) * kABytes;
+            const bool last_chunk = q + 1 == chunks;
+            const bool more = !last_chunk || has_next;     // a chunk follows this one
+            if (last_chunk && has_next) {   // the halo of this item is complete: re-aim the loaders
+                nxt = decode(item + 1);
+                set_a_off(nxt);
+                w_n0_next = nxt.n0 * 9 * a.Cin * 2;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            const int q_next = last_chunk ? 0 : q + 1;
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
+            for (int tap = 0; tap < 9; ++tap) {
+                // B(s+2) exists unless this is one of the last two steps
+                if (tap < 7 || more) wait_vm_lgkm0<PW>();
+                else wait_vm_lgkm0<0>();
+                if (!(OG_HALO_ABL & 2) && tap < NPA && more) issue_a(tap, q_next, (qq + 1) & 1);
+                const unsigned char *wB = bufB + ((qq + tap) & 3) * kBBytes;
+                const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
+                if (!(OG_HALO_ABL & 4) || (qq == 0 && tap == 0))
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[n][m] = OG_LP_MFMA(wf[kh][n], pf[kh][m], acc[n][m]);
-            __builtin_amdgcn_s_setprio(0);
-            {   // weight DMA behind the MFMA queue of this step (2 % faster in the network than issuing it in the R
-                // phase; the halo piece stays there: moving both costs 12 %)
-                const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9, q3 = tap + 3 < 9 ? q : q + 1;
-                if (q3 < chunks) issue_b(q3, t3, (q + tap + 3) & 3);
+                        pf[kh][m] = *reinterpret_cast<const bf16x8 *>(hA + px_off[m] + shift + kh * 64);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        wf[kh][n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if (!(OG_HALO_ABL & 8)) {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                acc[n][m] = OG_LP_MFMA(wf[kh][n], pf[kh][m], acc[n][m]);
+                } else {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(wf[kh][n]));
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(pf[kh][m]));
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                {   // weight DMA behind the MFMA queue of this step (2 % faster in the network than issuing it in the R
+                    // phase; the halo piece stays there: moving both costs 12 %)
+                    const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9;
+                    const bool wraps = tap + 3 >= 9;
+                    if (!(OG_HALO_ABL & 1) && (!wraps || more))
+                        issue_b(wraps && last_chunk ? w_n0_next : w_n0, wraps ? q_next : q, t3, (qq + tap + 3) & 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    if (wave < 4) __builtin_amdgcn_s_barrier();
+        if (wave < 4) __builtin_amdgcn_s_barrier();
 
-    CONV_STAMP(3);
-    // ---- epilogue: bias + ReLU + the one rounding happen in the accumulator layout (the residual is already in);
-    // the bf16 tile then goes through LDS ([tile pixels][128 couts], pitch 272 B: conflict-free ds_write_b64) so that
-    // global stores are 16 B per lane, 256 B contiguous per pixel.  (Storing the accumulator layout straight out
-    // -- 8 B per lane at a 512-B stride -- took 12 us of a 47 us workgroup; staging fp32 and adding the residual
-    // after it 8 us.)
-    constexpr int kOPitch = BN * 2 + 16, kTilePx = TW * TH;
-    static_assert(kTilePx * kOPitch <= 2 * kABytes + 4 * kBBytes, "output staging must fit the LDS of the main loop");
-    __syncthreads();  // all waves are done reading the last stage
+        HALO_CLOCK(7);
+        HALO_STAMP(3);
+        // ---- epilogue: bias + ReLU + the one rounding happen in the accumulator layout (the residual is already in);
+        // the bf16 tile then goes through LDS ([tile pixels][128 couts], pitch 272 B: conflict-free ds_write_b64) so that
+        // global stores are 16 B per lane, 256 B contiguous per pixel.  (Storing the accumulator layout straight out
+        // -- 8 B per lane at a 512-B stride -- took 12 us of a 47 us workgroup; staging fp32 and adding the residual
+        // after it 8 us.)  Last item of the workgroup: the whole tile at once, all of the LDS is free.  Otherwise the
+        // next item's first halo chunk and weight tiles are already in LDS: the tile goes out in two halves through the
+        // halo buffer of the chunk just finished, and the next item's residual loads are issued as soon as a wave's
+        // accumulators are in LDS, so they fly under the stores.
+        constexpr int kOPitch = BN * 2 + 16, kTilePx = TW * TH;
+        constexpr int kPerPx = BN / 8;
+        static_assert(kTilePx * kOPitch <= 2 * kABytes + 4 * kBBytes, "output staging must fit the LDS of the main loop");
+        static_assert(kTilePx / 2 * kOPitch <= kABytes && kTilePx % 2 == 0 && (kTilePx / 2) % 16 == 0, "half-tile staging must fit one halo buffer");
+        const size_t tile_px = (size_t)(cur.img * a.H + cur.ty * TH) * a.W + cur.tx * TW;
+        // bias in registers before the first store is issued: loads and stores share vmcnt, a bias load behind the first
+        // half's stores waited for them to drain (10 us per hand-over instead of 3)
+        f32x4 bias_r[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int px = (wm * MT + m) * 16 + fcol;
+        for (int n = 0; n < NT; ++n) bias_r[n] = *reinterpret_cast<const f32x4 *>(a.bias + cur.n0 + (wn * NT + n) * 16 + fk * 4);
+        auto stage = [&](unsigned char *base, int px0, int px1) {   // this wave's pixels in [px0, px1) -> LDS rows from base
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int cl = (wn * NT + n) * 16 + fk * 4;
-            f32x4 v = acc[n][m] + *reinterpret_cast<const f32x4 *>(a.bias + n0 + cl);
-            u16x4 o;
+            for (int m = 0; m < MT; ++m) {
+                const int px = (wm * MT + m) * 16 + fcol;
+                if ((wm * MT + m) * 16 < px0 || (wm * MT + m) * 16 >= px1) continue;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) o[jj] = f2bf(a.relu ? fmaxf(v[jj], 0.f) : v[jj]);
-            *reinterpret_cast<u16x4 *>(lds + px * kOPitch + cl * 2) = o;
+                for (int n = 0; n < NT; ++n) {
+                    const int cl = (wn * NT + n) * 16 + fk * 4;
+                    f32x4 v = acc[n][m] + bias_r[n];
+                    u16x4 o;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) o[jj] = f2bf(a.relu ? fmaxf(v[jj], 0.f) : v[jj]);
+                    *reinterpret_cast<u16x4 *>(base + (px - px0) * kOPitch + cl * 2) = o;
+                }
+            }
+        };
+        auto store_rows = [&](const unsigned char *base, int px0, int npx) {
+            const int groups = npx * kPerPx;
+            for (int g = tid; g < groups; g += 512) {
+                const int px = px0 + g / kPerPx, cg = g % kPerPx;
+                const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + cur.n0 + cg * 8;
+                const u16x8 v = *reinterpret_cast<const u16x8 *>(base + (px - px0) * kOPitch + cg * 16);
+                // Write-through keeps the Infinity Cache free of DIRTY activations (OG_CONV_STORE; measured: no difference)
+                if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a.out + off), "v"(v) : "memory");
+                else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a.out + off), "v"(v) : "memory");
+                else *reinterpret_cast<u16x8 *>(a.out + off) = v;
+            }
+        };
+        if (!has_next) {
+            __syncthreads();  // all waves are done reading the last stage
+            stage(lds, 0, kTilePx);
+            __syncthreads();
+            store_rows(lds, 0, kTilePx);
+            HALO_STAMP(5);
+            break;
         }
-    }
-    __syncthreads();
-    constexpr int kPerPx = BN / 8, kGroups = kTilePx * kPerPx;
-    static_assert(kGroups % 512 == 0, "tile pixels must be a multiple of 32");
-    const size_t tile_px = (size_t)(img * a.H + ty * TH) * a.W + tx * TW;
+        unsigned char *const stg = bufA + ((qq - 1) & 1) * kABytes;   // qq has moved on: the finished chunk's buffer
+        u16x4 sk[NT][MT];
+        // raw barriers with explicit LDS waits: __syncthreads() also drains vmcnt, i.e. waits for the previous half's
+        // global stores to be acknowledged (8.8 us per hand-over instead of 3)
+        auto lds_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        lds_barrier();   // all waves are done reading the last stage
 #pragma unroll
-    for (int i = 0; i < kGroups / 512; ++i) {
-        const int g = tid + 512 * i, px = g / kPerPx, cg = g % kPerPx;
-        const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + n0 + cg * 8;
-        const u16x8 v = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
-        // Write-through keeps the Infinity Cache free of DIRTY activations: the convolutions are MFMA-bound, so pushing
-        // their output to HBM at once costs them nothing, while dirty lines left behind are evicted on the clock of
-        // whatever memory-bound kernel comes next (the decoder's K1a / K1 paid 10-15 us for the backbone's leftovers).
-        if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a.out + off), "v"(v) : "memory");
-        else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a.out + off), "v"(v) : "memory");
-        else *reinterpret_cast<u16x8 *>(a.out + off) = v;
+        for (int h = 0; h < 2; ++h) {
+            stage(stg, h * (kTilePx / 2), (h + 1) * (kTilePx / 2));
+            if (h == 1) load_skip(nxt, sk);   // every accumulator of the workgroup is in LDS or already stored
+            lds_barrier();
+#ifdef OG_HALO_EPI_STAMPS
+            if (h == 0) HALO_STAMP(4); else HALO_STAMP(7);
+#endif
+            store_rows(stg, h * (kTilePx / 2), kTilePx / 2);
+            lds_barrier();
+#ifdef OG_HALO_EPI_STAMPS
+            if (h == 0) HALO_STAMP(6);
+#endif
+        }
+        HALO_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores and loads share the counter: drain, then start the steady state afresh
+        init_acc(sk);
+        ++item;
+        cur = nxt;
+        w_n0 = w_n0_next;
     }
-    CONV_STAMP(5);
+#undef HALO_STAMP
+#undef HALO_CLOCK
 }
 
 // Second launch of the two-launch form: one workgroup per output tile sums the ksplit slabs (coalesced 16 B per
@@ -845,6 +964,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
         { static const int policy = getenv("OG_CONV_STORE") ? atoi(getenv("OG_CONV_STORE")) : 0; h.store_policy = policy; }
         h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
+        { static const int items = getenv("OG_CONV_HALO_ITEMS") ? atoi(getenv("OG_CONV_HALO_ITEMS")) : 1; h.items = items < 1 ? 1 : items; }
         h.stamps = g_stamps;
         h.x_bytes = (int)(M * Cin * 2);
         h.w_bytes = Cout * 9 * Cin * 2;
@@ -856,7 +976,9 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
         if (attr_.need())                                                                                       \
             (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<TW_, TH_, WM_>,                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
-        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                       \
+        const long items_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                        \
+        if (items_ < 1024 * (long)h.items / 2) h.items = 1;   /* several items per workgroup only where the grid stays >= 2 x the CUs */ \
+        const long blocks_ = (items_ + h.items - 1) / h.items;                                                  \
         hipLaunchKernelGGL((conv3x3_halo_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(512), lds_, st, h); \
     } while (0)
         if (kind == 1) HALO_LAUNCH(16, 16, 4);

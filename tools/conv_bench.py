@@ -5,6 +5,7 @@ import argparse
 import os
 import sys
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -115,16 +116,30 @@ def main():
                 _flush.fill_(1)
                 torch.cuda.synchronize()
                 lib.og_conv3x3_debug_stamps(_lib.ptr(st))
-                ours(0)
+                for _ in range(8):   # back to back: the last launch (its marks stay) runs at the clock the chip holds under this load
+                    ours(0)
                 torch.cuda.synchronize()
                 lib.og_conv3x3_debug_stamps(None)
                 v = st.view(-1, 8).cpu().numpy()
+                later = np.nonzero((v[:, 0] == 0) & (v[:, 2] > 0) & (v[:, 5] > 0))[0]   # halo kernel: items after a workgroup's first
+                if len(later):
+                    prev_end = v[later - 1, 5]
+                    print('   later items of a workgroup (us, median): hand-over (previous stores issued -> loop) %.2f | loop %.2f | epilogue %.2f   (n=%d)'
+                          % (np.median((v[later, 2] - prev_end) / 100.0), np.median((v[later, 3] - v[later, 2]) / 100.0),
+                             np.median((v[later, 5] - v[later, 3]) / 100.0), len(later)))
+                if os.environ.get('OG_EPI_STAMPS') and len(later):
+                    e = v[later]
+                    seq = np.stack([e[:, 4] - e[:, 3], e[:, 6] - e[:, 4], e[:, 7] - e[:, 6], e[:, 5] - e[:, 7]], 1) / 100.0
+                    print('   hand-over epilogue (us, median): loop end -> half 0 staged %.2f | stores 0 issued %.2f | half 1 staged %.2f | stores 1 issued %.2f' % tuple(np.median(seq, 0)))
+                    v[:, 6:8] = 0
                 v = v[v[:, 0] > 0]
                 t0 = v[:, 0].min()
                 rel = (v - t0) / 100.0
-                import numpy as np
                 d = (v[:, [1, 2, 3, 5]] - v[:, [0, 1, 2, 3]]) / 100.0
                 ok = (v[:, 5] > 0) & (v[:, 3] > 0)
+                if (v[ok, 7] > 0).any():   # halo kernel: shader-clock counter beside the loop marks
+                    ghz = (v[ok, 7] - v[ok, 6]) / ((v[ok, 3] - v[ok, 2]) * 10.0)
+                    print('   shader clock over the main loop: median %.2f GHz (min %.2f, max %.2f)' % (np.median(ghz), ghz.min(), ghz.max()))
                 print('   per-workgroup phases (us, median): setup+issue %.2f | first data %.2f | loop %.2f | epilogue %.2f | total %.2f; kernel span %.1f'
                       % (*np.median(d[ok], 0), np.median((v[ok, 5] - v[ok, 0]) / 100.0), (v[ok, 5].max() - t0) / 100.0))
                 names = ['start', 'issued', 'first data', 'loop end', 'ticket', 'end(last)']
@@ -132,7 +147,6 @@ def main():
                 for i, nm in enumerate(names):
                     col = rel[:, i][v[:, i] > 0]
                     if len(col):
-                        import numpy as np
                         print(f'      {nm:11s} {np.median(col):7.2f} {col.max():7.2f}   (n={len(col)})')
             t = graph_time(ours, a.reps, cold=not a.warm)
             line += f' | {plan or "auto"}: {t:6.1f} us ({gflop / t * 1e-3:5.0f} TF) err {err:.1e}'
