@@ -51,7 +51,9 @@ __device__ long long g_k1_stamps[1024 * 16];
 namespace {
 
 #ifndef OG_K1_LOAD_AUX
-#define OG_K1_LOAD_AUX 2  // nt: the heatmap is streamed once (+8% read bandwidth measured on MI355X)
+#define OG_K1_LOAD_AUX 0  // default cache policy.  nt (2) reads an HBM-cold batch 2 us faster (56 vs 58 us for the two launches), but in the
+                          // decode pipeline the batch has just been written by K1a and sits in the Infinity Cache: there nt loads cost
+                          // 60 us (66 behind the backbone) against 57 -- tools/k1_bench.py, every policy (sc0, sc1, nt, combinations)
 #endif
 #ifndef OG_K1_BAND_PF
 #define OG_K1_BAND_PF 3

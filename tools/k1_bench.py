@@ -138,8 +138,8 @@ def main():
             res[f'single after {a.burst} ms of GEMM + K1a'] = timed(single, burst_then_k1a)
             res[f'two after {a.burst} ms of GEMM + K1a'] = timed(two, burst_then_k1a)
             res[f'three after {a.burst} ms of GEMM + K1a'] = timed(three, burst_then_k1a)
-        st = ws1[61440:65536].view(torch.int32).cpu().numpy()
-        rows = np.diff(st[16:16 + 257])
+        bal = ws1[61440:65536].view(torch.int32).cpu().numpy()
+        rows = np.diff(bal[16:16 + 257])
         print(f'== {tag}: single == two == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
         for name, (med, mn) in res.items():
             print(f'   {name:36s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
