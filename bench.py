@@ -335,7 +335,7 @@ def main():
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, profiles/README.md): only a figure
         # measured on THIS round's kernels is reported
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02_k1_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r02e_k1_traffic.json')
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
         imgs = a.batch * a.steps * world
@@ -353,8 +353,8 @@ def main():
             'per_rank_images_per_sec': per_rank,
             'poses_last_batch': [int(len(x)) for x in poses],
             'stage_us': {k: round(float(np.mean(v)), 2) for k, v in stage_us.items()},
-            'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + merge_bands_kernel + '
-                                   'collect_limbs_kernel',
+            'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
+                                   'merge_collect_kernel',
                          'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'us_per_launch': round(k1, 2), 'algorithmic_bytes_per_launch': int(k1_bytes)},

@@ -28,14 +28,14 @@ def main(fetch_csv, write_csv, out):
     wr = per_kernel(write_csv, 'WRITE_SIZE')
     names = sorted(set(rd) | set(wr))
     table = {n: {'read': round(rd.get(n, 0.0)), 'write': round(wr.get(n, 0.0))} for n in names}
-    three = [n for n in names if n.startswith(('band_topk_kernel', 'merge_bands_kernel', 'collect_limbs_kernel'))]
+    three = [n for n in names if n.startswith(('band_topk_kernel', 'merge_collect_kernel'))]   # og_generate_limbs_f32, flags 0
     single = [n for n in names if n.startswith('generate_limbs_kernel')]
     res = {'hbm_bytes_per_launch': round(sum(table[n]['read'] + table[n]['write'] for n in three)),
            'single_launch_hbm_bytes_per_launch': round(sum(table[n]['read'] + table[n]['write'] for n in single)) if single else None,
            'algorithmic_bytes_per_launch': 8 * 27889280,
            'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/k1_bench.py --iters 10 --rotate 3, bs8 '
                    '640x640); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads), '
-                   'values are KiB; hbm_bytes_per_launch = band_topk_kernel + merge_bands_kernel + collect_limbs_kernel '
+                   'values are KiB; hbm_bytes_per_launch = band_topk_kernel + merge_collect_kernel '
                    '(og_generate_limbs_f32, flags 0); calibration: bicubic4_kernel write = 222.8 MB expected',
            'per_kernel': table}
     json.dump(res, open(out, 'w'), indent=1)
