@@ -60,6 +60,10 @@ namespace {
 #endif
 constexpr int kPrefetch = OG_K1_BAND_PF;      // rows in flight per lane: 3 (2 .. 3 measured best on MI355X: 56.7 us for the three launches, 4: 60.4,
                                               // 6 / 8: 63.2, 1: 68; deeper queues lose -- more DRAM rows open at once, not occupancy)
+#ifndef OG_K1_BAND_ABL
+#define OG_K1_BAND_ABL 0
+#endif
+constexpr int kBandAbl = OG_K1_BAND_ABL;   // tuning harness, see band_topk_kernel
 constexpr int kInterior = 62;     // interior lanes per wave panel
 constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
 constexpr uint32_t kLaneOob = 0x80000000u;  // offset of lanes outside the image
@@ -357,7 +361,8 @@ struct WaveSeg {
     }
 };
 
-// ABL (tuning harness only): 0 = product; 1 = compute the admission masks but never push.
+// ABL (tuning harness only, -DOG_K1_BAND_ABL): 0 = product; 1 = compute the admission masks but never push; 3 = loads and
+// threshold ballots only.
 // FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
 // the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
 template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false>
@@ -507,6 +512,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             seg.cnt += (int)(any >> 63);  // keep the masks alive
             return;
         }
+        if (ABL == 3) return;   // harness: loads + threshold ballots only (the access pattern's own ceiling)
         if (any != 0ull) {
             Px<VEC> m;
             if (NMS_MODE) m = vmax3<VEC>(ha, hb, hc);
@@ -786,7 +792,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
                            cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded,
                            helper);
     else if (p.vec == 4)
-        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys, cnts,
                            hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,

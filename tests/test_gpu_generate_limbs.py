@@ -70,7 +70,8 @@ def maps(seed, n, h, w, dev, persons=4):
 
 
 @pytest.mark.parametrize("n,size,k", [(2, (256, 256), 32), (1, (640, 640), 32), (3, (384, 512), 48), (2, (128, 640), 16),
-                                       (8, (256, 256), 64), (1, (64, 64), 9), (5, (512, 256), 1)])
+                                       (8, (256, 256), 64), (1, (64, 64), 9), (5, (512, 256), 1),
+                                       (2, (320, 320), 100)])   # k > 64: the persistent kernel declines, both flags run the two launches
 def test_single_launch_matches_oracle_and_three_launch(dev, n, size, k):
     hr, off, t_hr, t_off = maps(500 + n + k, n, size[0], size[1], dev)
     limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev)
