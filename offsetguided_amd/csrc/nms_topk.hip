@@ -69,8 +69,13 @@ constexpr int kMaxWaves = 16;     // waves per workgroup (panels per row)
 constexpr uint32_t kLaneOob = 0x80000000u;  // offset of lanes outside the image
 constexpr uint32_t kRowOob = 0x40000000u;   // offset of rows the band must not read
 constexpr int kHistBins = 256;              // per-plane score histogram (NMS mode)
-constexpr int kHistShift = 20;              // bin = exponent (8 bits) + top 3 mantissa bits
-constexpr int kHistBase = (127 - 30) << 3;  // bin 0 starts at 2^-30 (everything smaller joins it)
+#ifndef OG_K1_HIST_MBITS
+#define OG_K1_HIST_MBITS 3
+#endif
+constexpr int kHistMBits = OG_K1_HIST_MBITS;                       // bin = exponent + top kHistMBits mantissa bits
+constexpr int kHistShift = 23 - kHistMBits;
+constexpr int kHistBase = (127 + 2 - (kHistBins >> kHistMBits)) << kHistMBits;   // the bins end at 2^2; 3 bits: bin 0 starts at 2^-30,
+                                                                                  // 4 bits: 2^-14 (everything smaller joins bin 0)
 constexpr uint64_t kWsMagic = 0x4f47444543303031ull;  // workspace self-validation word
 
 __device__ __forceinline__ int hist_bin(int bits)
