@@ -522,12 +522,22 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             Px<VEC> m;
             if (NMS_MODE) m = vmax3<VEC>(ha, hb, hc);
             const uint32_t base = (uint32_t)row * (uint32_t)W + (uint32_t)g.col;
+            // all four masks before the first push: most wave-rows that reach this point hold pixels above the threshold
+            // that are not peaks (the flanks of a blob), and leave through ONE branch instead of four.  A push may raise
+            // tau (compaction); the later components are then admitted against the older, lower bound: still exact.
+            bool pj[VEC];
+            uint64_t mj[VEC], many = 0;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {  // tau may rise between components (compaction): test per component
-                const bool p = NMS_MODE ? ((__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits) && (v.c[j] == m.c[j]))
-                                        : (v.c[j] >= seg.lane_tau_f);
-                const uint64_t mj = __builtin_amdgcn_ballot_w64(p);
-                if (mj != 0ull) seg.template push<NMS_MODE>(p, mj, v.c[j], base + j, k);
+            for (int j = 0; j < VEC; ++j) {
+                pj[j] = NMS_MODE ? ((__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits) && (v.c[j] == m.c[j]))
+                                 : (v.c[j] >= seg.lane_tau_f);
+                mj[j] = __builtin_amdgcn_ballot_w64(pj[j]);
+                many |= mj[j];
+            }
+            if (many != 0ull) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (mj[j] != 0ull) seg.template push<NMS_MODE>(pj[j], mj[j], v.c[j], base + j, k);
             }
         }
     };
