@@ -508,11 +508,15 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         // tests and the masks are only evaluated for wave-rows that hold a pixel >= tau (the horizontal
         // maxima stay incremental: recomputing all three rows on demand measured slower).  Fewer
         // instructions per row keep the kernel HBM-bound when the chip clocks down behind the backbone.
-        uint64_t any = 0;
+        // (masks are built from ballots of plain compares and combined on the scalar side: a ballot of `a && b` is
+        // lowered through a 0/1 VGPR -- v_cndmask + v_cmp_ne per component)
+        uint64_t ge[VEC], any = 0;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            any |= __builtin_amdgcn_ballot_w64(NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits)
-                                                        : (v.c[j] >= seg.lane_tau_f));
+        for (int j = 0; j < VEC; ++j) {
+            ge[j] = __builtin_amdgcn_ballot_w64(NMS_MODE ? (__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits)
+                                                         : (v.c[j] >= seg.lane_tau_f));
+            any |= ge[j];
+        }
         if (ABL == 1) {
             seg.cnt += (int)(any >> 63);  // keep the masks alive
             return;
@@ -525,19 +529,18 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             // all four masks before the first push: most wave-rows that reach this point hold pixels above the threshold
             // that are not peaks (the flanks of a blob), and leave through ONE branch instead of four.  A push may raise
             // tau (compaction); the later components are then admitted against the older, lower bound: still exact.
-            bool pj[VEC];
             uint64_t mj[VEC], many = 0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                pj[j] = NMS_MODE ? ((__builtin_bit_cast(int, v.c[j]) >= seg.lane_tau_bits) && (v.c[j] == m.c[j]))
-                                 : (v.c[j] >= seg.lane_tau_f);
-                mj[j] = __builtin_amdgcn_ballot_w64(pj[j]);
+                mj[j] = NMS_MODE ? (ge[j] & __builtin_amdgcn_ballot_w64(v.c[j] == m.c[j])) : ge[j];
                 many |= mj[j];
             }
             if (many != 0ull) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    if (mj[j] != 0ull) seg.template push<NMS_MODE>(pj[j], mj[j], v.c[j], base + j, k);
+                    if (mj[j] != 0ull)   // the lane predicate IS the mask (a predicate recomputed here would see a tau that an
+                                         // earlier component's compaction has raised, and leave holes in the segment)
+                        seg.template push<NMS_MODE>(__builtin_amdgcn_inverse_ballot_w64(mj[j]), mj[j], v.c[j], base + j, k);
             }
         }
     };

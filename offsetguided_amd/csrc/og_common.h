@@ -56,11 +56,11 @@ __device__ __forceinline__ int og_xcd_remap(int bid, int padded)
 // Whole-wave shifts by one lane (gfx9 DPP wave_shr / wave_shl); lanes without a source get 0.
 __device__ __forceinline__ float og_from_lane_below(float v)  // lane i <- lane i-1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   // bound_ctrl: lane 0 gets 0, no `old` register to clear
 }
 __device__ __forceinline__ float og_from_lane_above(float v)  // lane i <- lane i+1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ float og_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
