@@ -34,6 +34,8 @@
 // with a larger mmax; the table then lives in the caller's global workspace instead of LDS).
 #include <math.h>
 
+#include <type_traits>
+
 #include "og_common.h"
 
 namespace {
@@ -60,7 +62,6 @@ struct GroupArgs {
     float *poses;
     int32_t *counts, *status;
     float *gsub;  // global subset tables (N x mmax x nkp x 6) or nullptr -> LDS
-    int limbs_in_lds;  // stage the image's whole limbs block (L*K*13 floats) in LDS up front
 };
 
 __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairwise add.reduce, n <= 17
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_anyA, s_anyB, s_anyQ, s_M, s_P, s_overflow, s_kept, s_new0, s_nnew;
+    __shared__ int s_anyA, s_anyB, s_anyQ, s_M, s_kept;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = A.K, L = A.L, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax, LK = L * K;
     // ---- LDS carve-up (pure pointer arithmetic: an integer round trip for alignment would turn
@@ -132,6 +133,7 @@ greedy_group_kernel(GroupArgs A)
 #define SUBP(ph, j, f) sub[((ph) * nkp + (j)) * 6 + (f)]
 #define LIM(c, f) lim_l[(c) * 11 + (f)]
 
+    // (staging the image's 31 KB limbs block in LDS with one coalesced pass was measured: no gain, U1 and U4 below take 2 us each)
     const float *limbs = A.limbs + (size_t)img * LK * 13;
     K3_STAMP_INIT;
     // ================= up-front: every limb type at once =================
@@ -146,66 +148,114 @@ greedy_group_kernel(GroupArgs A)
     }
     for (int i = tid; i < L; i += kThreads) kk_arr[i] = 0;
     for (int i = tid; i < K; i += kThreads) { c_n1[i] = 0; c_n2[i] = 0; }
-    if (tid == 0) { s_M = 0; s_P = 0; s_overflow = 0; s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
+    if (tid == 0) { s_M = 0; s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
     __syncthreads();
+    K3_STAMP(7);
     // U2. stable descending rank (:232) and "a better row owns my to-index" (:233-239).  One thread per
     // candidate, serial over the K rivals of its limb type (runtime integer divisions per (k, j) cell
     // cost more than the loop)
-    for (int lk = tid; lk < LK; lk += kThreads) {
-        const float s = t_score[lk];
-        if (s == -INFINITY) continue;
-        const int l = lk / K, k = lk - l * K, base = l * K, my_i2 = t_i2[lk];
-        int rank = 0, dup = 0;
-        int j = 0;
-        if (wide_ok) {  // rows start on 16 bytes: four rivals per pair of ds_read_b128
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            for (; j < K; j += 4) {
-                const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
-                const v4i i4 = *reinterpret_cast<const v4i *>(t_i2 + base + j);
+    // (K == 32, every published configuration: the eight steps are unrolled so that all sixteen wide LDS reads are in flight
+    // together -- the rolled loop waits for LDS once per step, 9 us for this pass instead of 3)
+    auto rank_pass = [&](auto steps_tag) {
+        constexpr int STEPS = decltype(steps_tag)::value;   // K / 4 when K is known at compile time, 0 = generic
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        for (int lk = tid; lk < LK; lk += kThreads) {
+            const float s = t_score[lk];
+            if (s == -INFINITY) continue;
+            const int l = STEPS ? lk / (STEPS * 4) : lk / K, k = lk - l * K, base = l * K, my_i2 = t_i2[lk];
+            int rank = 0, dup = 0;
+            int j = 0;
+            if constexpr (STEPS > 0) {
+                v4f o4[STEPS];
+                v4i i4[STEPS];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool better = o4[e] != -INFINITY && (o4[e] > s || (o4[e] == s && j + e < k));
-                    rank += better;
-                    dup |= better && (i4[e] == my_i2);
+                for (int q = 0; q < STEPS; ++q) {
+                    o4[q] = *reinterpret_cast<const v4f *>(t_score + base + 4 * q);
+                    i4[q] = *reinterpret_cast<const v4i *>(t_i2 + base + 4 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < STEPS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // bitwise, not short-circuit: `&&` / `||` compile to nested exec-mask branches here (20 instructions and
+                        // three branches per rival).  A rival without a score holds -inf: never > s, never == s (s is finite)
+                        const int better = (int)(o4[q][e] > s) | ((int)(o4[q][e] == s) & (int)(4 * q + e < k));
+                        rank += better;
+                        dup |= better & (int)(i4[q][e] == my_i2);
+                    }
+                j = K;
+            } else if (wide_ok) {  // rows start on 16 bytes: four rivals per pair of ds_read_b128
+                for (; j < K; j += 4) {
+                    const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
+                    const v4i i4 = *reinterpret_cast<const v4i *>(t_i2 + base + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int better = (int)(o4[e] > s) | ((int)(o4[e] == s) & (int)(j + e < k));
+                        rank += better;
+                        dup |= better & (int)(i4[e] == my_i2);
+                    }
                 }
             }
-        }
-        for (; j < K; ++j) {
-            const float o = t_score[base + j];
-            const bool better = o != -INFINITY && (o > s || (o == s && j < k));
-            rank += better;
-            dup |= better && (t_i2[base + j] == my_i2);
-        }
-        t_rank[lk] = rank;
-        t_dup[lk] = dup;
-    }
-    __syncthreads();
-    // U3. position among the surviving rows
-    for (int lk = tid; lk < LK; lk += kThreads) {
-        const float s = t_score[lk];
-        if (s == -INFINITY || t_dup[lk]) continue;
-        const int l = lk / K, k = lk - l * K, base = l * K;
-        int urank = 0;
-        int j = 0;
-        if (wide_ok) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            for (; j < K; j += 4) {
-                const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
-                const v4i d4 = *reinterpret_cast<const v4i *>(t_dup + base + j);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    urank += (o4[e] != -INFINITY) && !d4[e] && (o4[e] > s || (o4[e] == s && j + e < k));
+            for (; j < K; ++j) {
+                const float o = t_score[base + j];
+                const int better = (int)(o > s) | ((int)(o == s) & (int)(j < k));
+                rank += better;
+                dup |= better & (int)(t_i2[base + j] == my_i2);
             }
+            t_rank[lk] = rank;
+            t_dup[lk] = dup;
         }
-        for (; j < K; ++j) {
-            const float o = t_score[base + j];
-            urank += (o != -INFINITY) && !t_dup[base + j] && (o > s || (o == s && j < k));
-        }
-        t_urank[lk] = urank;
-    }
+    };
+    if (K == 32 && wide_ok) rank_pass(std::integral_constant<int, 8>());
+    else rank_pass(std::integral_constant<int, 0>());
     __syncthreads();
+    K3_STAMP(8);
+    // U3. position among the surviving rows
+    auto urank_pass = [&](auto steps_tag) {
+        constexpr int STEPS = decltype(steps_tag)::value;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        for (int lk = tid; lk < LK; lk += kThreads) {
+            const float s = t_score[lk];
+            if (s == -INFINITY || t_dup[lk]) continue;
+            const int l = STEPS ? lk / (STEPS * 4) : lk / K, k = lk - l * K, base = l * K;
+            int urank = 0;
+            int j = 0;
+            if constexpr (STEPS > 0) {
+                v4f o4[STEPS];
+                v4i d4[STEPS];
+#pragma unroll
+                for (int q = 0; q < STEPS; ++q) {
+                    o4[q] = *reinterpret_cast<const v4f *>(t_score + base + 4 * q);
+                    d4[q] = *reinterpret_cast<const v4i *>(t_dup + base + 4 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < STEPS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        urank += (int)(d4[q][e] == 0) & ((int)(o4[q][e] > s) | ((int)(o4[q][e] == s) & (int)(4 * q + e < k)));
+                j = K;
+            } else if (wide_ok) {
+                for (; j < K; j += 4) {
+                    const v4f o4 = *reinterpret_cast<const v4f *>(t_score + base + j);
+                    const v4i d4 = *reinterpret_cast<const v4i *>(t_dup + base + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        urank += (int)(d4[e] == 0) & ((int)(o4[e] > s) | ((int)(o4[e] == s) & (int)(j + e < k)));
+                }
+            }
+            for (; j < K; ++j) {
+                const float o = t_score[base + j];
+                urank += (int)(t_dup[base + j] == 0) & ((int)(o > s) | ((int)(o == s) & (int)(j < k)));
+            }
+            t_urank[lk] = urank;
+        }
+    };
+    if (K == 32 && wide_ok) urank_pass(std::integral_constant<int, 8>());
+    else urank_pass(std::integral_constant<int, 0>());
+    __syncthreads();
+    K3_STAMP(9);
     // U4. stage the surviving rows in sorted order
     for (int i = tid; i < LK; i += kThreads) {
         if (t_score[i] == -INFINITY || t_dup[i]) continue;
@@ -222,12 +272,16 @@ greedy_group_kernel(GroupArgs A)
     K3_STAMP(0);
     // ================= serial over limb types =================
     // invariant at the top: r_a = r_b = r_p = -1, r_d = 0 for rows < M; c_n1 = c_n2 = 0; flags = 0
+    // M_rows (live rows) and P_rows (physical rows ever created) are kept by every wave in registers: they change by
+    // wave-uniform arithmetic (new rows) or through s_M behind a barrier (merges)
+    int M_rows = 0, P_rows = 0;
+    bool overflow = false;
     for (int l = 0; l < L; ++l) {
         const int kk = kk_arr[l];
         if (kk == 0) continue;  // uniform
         const int jf = A.jf[l], jt = A.jt[l];
         const float *lim_l = lim_all + (size_t)l * K * 11;
-        const int m0 = s_M;
+        const int m0 = M_rows;
         bool anyA = false, anyB = false;
         if (m0 > 0) {
             // ---- match against the subset table (:87-135): lanes = (row, column) cells ----
@@ -239,7 +293,7 @@ greedy_group_kernel(GroupArgs A)
                 const int idf = (int)SUBP(ph, jf, 5), idt = (int)SUBP(ph, jt, 5);
                 const float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4), sc = LIM(c, 8);
                 const int ms = (idf == (int)LIM(c, 9)) + (idt == (int)LIM(c, 10));
-                const bool rep = sc > lst || sc > lsf;
+                const bool rep = (int)(sc > lst) | (int)(sc > lsf);
                 if (ms == 2) { atomicAdd(&c_n2[c], 1); if (rep) { r_a[m] = c; s_anyA = 1; } }
                 if (ms == 1) { atomicAdd(&c_n1[c], 1); if (rep) { atomicMax(&r_b[m], c); s_anyB = 1; } }
             }
@@ -266,7 +320,8 @@ greedy_group_kernel(GroupArgs A)
             anyB = s_anyB != 0;
             // ---- merge rows sharing exactly two keypoints (:140-161): lanes = row pairs ----
             if (m0 >= 2) {
-                // 16 x 16 tiles of (a, b) over the upper triangle: no index decoding, no divisions
+                // 16 x 16 tiles of (a, b) over the upper triangle: no index decoding, no divisions (one pair per lane in row-major
+                // order of the triangle needs a third fewer rounds at 30 rows, but its index decoding costs more than that)
                 const int ta_n = (m0 + 15) >> 4;
                 for (int ta = 0; ta < ta_n; ++ta)
                     for (int tb = ta; tb < ta_n; ++tb) {
@@ -281,7 +336,7 @@ greedy_group_kernel(GroupArgs A)
                             for (int q = 0; q < 5; ++q) {  // unused tail entries hold -1 in every row
                                 const v4i va = ra[q], vb = rb[q];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) cnt += (va[e] == vb[e] && va[e] != -1);
+                                for (int e = 0; e < 4; ++e) cnt += (int)(va[e] == vb[e]) & (int)(va[e] != -1);   // bitwise: no exec-mask branches
                             }
                             if (cnt == 2) { atomicMax(&r_p[a], b); r_d[b] = 1; s_anyQ = 1; }
                         }
@@ -315,20 +370,22 @@ greedy_group_kernel(GroupArgs A)
                         if (lane == 0) s_M = newM;
                     }
                     __syncthreads();
+                    M_rows = s_M;
                 }
             }
         }
         K3_STAMP(3);
-        // ---- unmatched limbs start new rows (:166-177): wave 0 assigns slots, everyone fills ----
-        if (wave == 0) {
-            int M = s_M, P = s_P, n_tot = 0;
+        // ---- unmatched limbs start new rows (:166-177).  EVERY wave works out the same slot assignment (ballot + popcount
+        // over the kk columns; identical values stored by all four), so no barrier stands between it and the fill ----
+        {
+            int M = M_rows, P = P_rows, n_tot = 0;
             for (int c0 = 0; c0 < kk; c0 += 64) {
                 const int c = c0 + lane;
                 bool fresh = false;
                 if (c < kk) fresh = (c_n2[c] * (anyA ? -1 : 2) + c_n1[c] * (anyB ? -1 : 1)) == 0;
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(fresh);
                 const int n_new = __builtin_popcountll(mask);
-                if (P + n_new > mmax) { if (lane == 0) s_overflow = 1; break; }
+                if (P + n_new > mmax) { overflow = true; break; }
                 const int off = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 if (fresh) {
                     order[M + off] = P + off;
@@ -338,13 +395,14 @@ greedy_group_kernel(GroupArgs A)
                 P += n_new;
                 n_tot += n_new;
             }
-            if (lane == 0) { s_new0 = s_P; s_nnew = n_tot; s_M = M; s_P = P; }
-        }
-        __syncthreads();
-        K3_STAMP(4);
-        if (s_overflow) break;  // uniform
-        {
-            const int n_new = s_nnew, p_first = s_new0, M = s_M;
+            if (overflow) break;  // uniform: every wave computed the same
+            const int n_new = n_tot, p_first = P_rows;
+            M_rows = M;
+            P_rows = P;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave reads the c_newcol entries it has just written
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            K3_STAMP(4);
             for (int r = tid >> 7; r < n_new; r += kThreads >> 7) {        // 128 lanes per new row (rowf <= 102)
                 const int jf6 = tid & 127;
                 if (jf6 >= rowf) continue;
@@ -364,12 +422,12 @@ greedy_group_kernel(GroupArgs A)
         K3_STAMP(5);
     }
 
-    if (s_overflow) {
+    if (overflow) {
         if (tid == 0) { A.status[img] = 1; A.counts[img] = 0; }
         return;
     }
     // ================= _delete_sort (:187-219) =================
-    const int M = s_M;
+    const int M = M_rows;
     if (tid == 0) s_kept = 0;
     __syncthreads();
     for (int m = tid; m < M; m += kThreads) {
@@ -397,7 +455,7 @@ greedy_group_kernel(GroupArgs A)
             bool ahead = false;
             if (j < M && !r_d[j]) {
                 const double o = r_score[j];
-                ahead = o > s || (o == s && j < m);
+                ahead = (int)(o > s) | ((int)(o == s) & (int)(j < m));
             }
             rank += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ahead));
         }
@@ -446,7 +504,7 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
     GroupArgs a;
     a.limbs = limbs; a.jf = jf; a.jt = jt; a.L = L; a.K = k; a.nkp = n_kp; a.use_scale = use_scale;
     a.sort_dim = sort_dim; a.mmax = mmax; a.person_thre = person_thre; a.dist_max = dist_max;
-    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr; a.limbs_in_lds = 0;
+    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr;
     size_t lds = staging_bytes(L, k, mmax);
     OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: L*k=%d candidates (and mmax=%d) do not fit in LDS", name, L * k, mmax);
     const size_t table = (size_t)mmax * n_kp * 6 * sizeof(float);
@@ -467,3 +525,7 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
+
+#ifdef OG_K3_STAMPS   // tuning harness (tools/k3_stamps.py): cycle counts per phase of image 0's workgroup
+OG_API void og_k3_debug_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k3_stamps), sizeof(g_k3_stamps)); }
+#endif
