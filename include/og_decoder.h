@@ -135,11 +135,16 @@ int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const fl
  *   writes the limb rows.  Shapes it does not take (W % 4 != 0, k > 64, planes much smaller than a workgroup's share of
  *   rows) silently run as flags 0.  Measured slower than flags 0 at bs8 640x640, kept
  *   as the basis of the next step.
+ * flags OG_LIMBS_TAIL_IN_BAND: the band top-k launch of flags 0 does the rest as well, by last arrivers -- the band that
+ *   finishes a plane last merges its lists, the plane that completes a limb type's two joint planes last pairs that limb
+ *   type.  One launch, nobody waits; measured 2 us slower than flags 0 (the hand-offs are memory round trips on the path of
+ *   the last plane), kept tested.  Shapes it does not take (W % 4 != 0, very large N * L) run as flags 0.
  * workspace: og_generate_limbs_workspace_bytes(N, C, H, W, k), 16-byte aligned, ZERO-FILLED ONCE by the caller
  * (hipMemset) before its first use; every call leaves it ready for the next one (any shape, any flags).  Its first
  * 64 KiB hold the only state that outlives a call (tickets, all zero between calls, and the row partition the
  * persistent kernel's feedback step maintains).  One call at a time per workspace. */
 #define OG_LIMBS_SINGLE_LAUNCH 1
+#define OG_LIMBS_TAIL_IN_BAND 2
 int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
                           const float *scales, int scales_mode, const float *jitter, int jitter_mode,
                           int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,

@@ -370,11 +370,106 @@ struct WaveSeg {
 // threshold ballots only.
 // FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
 // the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
-template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false>
-__global__ void __launch_bounds__(64 * kMaxWaves)
+// One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
+// this the same number of times: it contains workgroup barriers).  `all` / `flt`: n_all = nbands * k keys each, in LDS;
+// `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
+// SC1: the band lists were written in THIS launch by other workgroups (sc1 stores): read them with sc1 loads.
+template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit>
+__device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, const int *__restrict__ gc, uint64_t *all,
+                                            uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
+                                            const float *__restrict__ p, int H, int W, int k, int nbands, int t_sub, Emit &&emit)
+{
+    const int n_all = nbands * k, lane = tid & 63;
+    // keys and band counts are fetched together (one memory round trip), masked afterwards
+    if constexpr (SC1) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(gk), 0, n_all * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(gc), 0, nbands * 4, 0x00020000);
+        for (int i = tid; i < n_all; i += nthr) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(kr, i * 8, 0, 16);
+            const int c = __builtin_amdgcn_raw_buffer_load_b32(cr, (i / k) * 4, 0, 16);
+            all[i] = (i % k < c) ? (((uint64_t)t.y << 32) | t.x) : 0ull;
+        }
+    } else
+    for (int i = tid; i < n_all; i += nthr) {
+        const uint64_t key = gk[i];
+        const int c = gc[i / k];
+        all[i] = (i % k < c) ? key : 0ull;
+    }
+    if (tid == 0) { *s_bound = 0ull; *s_nf = 0; }
+    __syncthreads();
+    // A) k-th largest of the subset {first t_sub keys of each band}
+    const int n_sub = nbands * t_sub;
+    for (int i = tid; i < n_sub; i += nthr) flt[i] = all[(i / t_sub) * k + i % t_sub];
+    __syncthreads();
+    for (int i = tid; i < n_sub; i += nthr) {
+        const uint64_t mine = flt[i];
+        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) *s_bound = mine;
+    }
+    __syncthreads();
+    const uint64_t bound = *s_bound;
+    // B) keys >= bound (order does not matter: ranks are recomputed)
+    for (int i = tid; i < n_all; i += nthr) {
+        const uint64_t key = all[i];
+        if (key != 0ull && key >= bound) flt[atomicAdd(s_nf, 1)] = key;
+    }
+    __syncthreads();
+    const int nf = *s_nf;
+    // C) rank and emit
+    for (int i = tid; i < nf; i += nthr) {
+        const uint64_t mine = flt[i];
+        const int rank = og_count_greater(flt, nf, mine);
+        if (rank < k) emit(rank, og_key_value(mine), (long)og_key_index(mine));
+    }
+    int t = min(nf, k);
+    if (NMS_MODE && t < k && tid < 64) {
+        // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
+        // zero (ties at 0.0 broken by index, like every other tie)
+        auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
+        const long hw = (long)H * W;
+        for (long base = 0; base < hw && t < k; base += 64) {
+            const long i = base + lane;
+            bool zero = false;
+            if (i < hw) {
+                const int y = (int)(i / W), x = (int)(i % W);
+                const float v = px(y, x);
+                float m = (y == 0 || x == 0 || y == H - 1 || x == W - 1) ? 0.f : -INFINITY;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int yy = y + dy, xx = x + dx;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, px(yy, xx));
+                    }
+                zero = !(v == m && v != 0.f);
+            }
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(zero);
+            const int slot = t + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (zero && slot < k) emit(slot, 0.f, i);
+            t += __builtin_popcountll(mask);
+        }
+    }
+}
+
+// TAIL (og_generate_limbs_f32): the rest of generate_limbs inside this launch, by last arrivers --
+//   the band that finishes a plane LAST merges the plane's band lists and writes its (k) list;
+//   the plane that completes a limb type's pair of joint planes LAST pairs that limb type (one wave per limb type);
+//   the plane that finishes last of all validates the workspace for the next call.
+// Hand-offs: sc1 stores, s_waitcnt vmcnt(0), barrier, one relaxed agent-scope atomic add whose returned value names the
+// last arriver, which reads with sc1 loads; every ticket is back at zero when the launch ends.  Nobody waits for anybody.
+struct TailArgs {
+    int *tickets;            // [planes] plane tickets | [N * L] limb tickets | [1] planes done -- all zero between launches
+    float *out_scores;       // (planes, k)
+    int64_t *out_inds;
+    og_collect::Args ca;
+    int nd, t_sub, planes;
+};
+
+template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false, bool TAIL = false>
+// (amdgpu_waves_per_eu: <= 96 VGPRs -- at bs8 640x640 all 1 088 workgroups must be resident together, 5 per CU)
+__global__ void __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(5)))
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
-                 int *__restrict__ hist_all, const uint64_t *__restrict__ ws_magic, uint64_t magic,
-                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded, int helper)
+                 int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
+                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded, int helper,
+                 TailArgs tl)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
     // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
@@ -561,15 +656,119 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     int total_keys = 0;
     for (int w = 0; w < nwaves; ++w) total_keys += s_cnt[w];
     uint64_t *out = band_keys + ((size_t)plane * nbands + band) * k;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t okr = __builtin_amdgcn_make_buffer_rsrc(out, 0, k * 8, 0x00020000);
     for (int t = threadIdx.x; t < total_keys; t += blockDim.x) {
         int w = 0, o = t;
         while (o >= s_cnt[w]) { o -= s_cnt[w]; ++w; }
         const uint64_t key = smem[(size_t)s_slot[w] * cap + o];
         int rank = 0;
         for (int w2 = 0; w2 < nwaves; ++w2) rank += og_count_greater(smem + (size_t)s_slot[w2] * cap, s_cnt[w2], key);
-        if (rank < k) out[rank] = key;
+        if (rank < k) {
+            if constexpr (TAIL) {
+                u32x2 v;
+                v.x = (uint32_t)key;
+                v.y = (uint32_t)(key >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(v, okr, rank * 8, 0, 16);   // sc1: write-through
+            } else {
+                out[rank] = key;
+            }
+        }
     }
-    if (threadIdx.x == 0) band_cnt[(size_t)plane * nbands + band] = min(total_keys, k);
+    if constexpr (!TAIL) {
+        if (threadIdx.x == 0) band_cnt[(size_t)plane * nbands + band] = min(total_keys, k);
+    } else {
+        const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+        int *s_flag = s_cnt;   // the per-wave counts are not needed any more
+        if (tid == 0) {
+            const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(band_cnt + (size_t)plane * nbands, 0, nbands * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(min(total_keys, k), cr, band * 4, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(tl.tickets + plane, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == nbands - 1;
+            if (last) __hip_atomic_store(tl.tickets + plane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            s_flag[0] = last;
+        }
+        __syncthreads();
+        if (!s_flag[0]) return;
+        // ---- this band finished the plane: merge its band lists (LDS of the stream is free now) ----
+        // LDS of the tail (band_tail_lds_bytes): [all | flt] merge buffers, bound, count, to-do list, per wave 4 lists + scratch
+        const int n_all = nbands * k, Kp = (k + 3) & ~3;
+        uint64_t *all = smem, *flt = smem + n_all;
+        uint64_t *s_bound = smem + 2 * (size_t)n_all;
+        int *s_nf = reinterpret_cast<int *>(s_bound + 1);
+        int *s_todo = s_nf + 1;                   // [0] count, [1..] limb types this workgroup pairs
+        __syncthreads();                          // s_flag read by everyone before the region is reused
+        if (hist_all)   // the plane's slot table is no longer read: leave it clean for the next call
+            for (int i = tid; i < nbands; i += nthr) hist_all[(size_t)plane * nbands + i] = 0;
+        float *os = tl.out_scores + (size_t)plane * k;
+        int64_t *oi = tl.out_inds + (size_t)plane * k;
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(os, 0, k * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(oi, 0, k * 8, 0x00020000);
+        merge_plane<true, false, true>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, all, flt, s_bound,
+                                       s_nf, tid, nthr, in + (size_t)plane * H * W, H, W, k, nbands, tl.t_sub,
+                                       [&](int rank, float v, long idx) {
+                                           u32x2 w;
+                                           w.x = (uint32_t)idx;
+                                           w.y = 0u;   // flat indices are < 2^27
+                                           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), sr, rank * 4, 0, 16);
+                                           __builtin_amdgcn_raw_buffer_store_b64(w, ir, rank * 8, 0, 16);
+                                       });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) s_todo[0] = 0;
+        __syncthreads();
+        // ---- limb types that use this plane: the second of their two planes pairs them ----
+        const int C = tl.ca.C, L = tl.ca.L, n = plane / C, c = plane - n * C;
+        int *limb_tickets = tl.tickets + tl.planes + n * L;
+        for (int l = tid; l < L; l += nthr) {
+            const int hit = (tl.ca.jf[l] == c) + (tl.ca.jt[l] == c);
+            if (hit) {
+                const int old = __hip_atomic_fetch_add(limb_tickets + l, hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + hit == 2) {
+                    __hip_atomic_store(limb_tickets + l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_todo[1 + atomicAdd(&s_todo[0], 1)] = l;
+                }
+            }
+        }
+        if (tid == 0) {   // the last plane of all: every slot table is clean, the workspace is valid for this geometry again
+            int *done = tl.tickets + tl.planes + (tl.planes / C) * L;
+            const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == tl.planes - 1) {
+                __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *ws_magic = hist_all ? magic : 0ull;
+            }
+        }
+        __syncthreads();
+        const int ntodo = s_todo[0];
+        // one wave per limb type: both (k) lists by sc1 loads into the wave's LDS scratch, then collect_body.h
+        float *wl = reinterpret_cast<float *>(smem) + ((4 * n_all + 2 + 2 + L + 1 + 3) & ~3) + (size_t)wave * 8 * Kp;   // 16-byte aligned
+        for (int t = wave; t < ntodo; t += nwaves) {
+            const int l = s_todo[1 + t];
+            const int pf = n * C + tl.ca.jf[l], pt = n * C + tl.ca.jt[l];
+            float *lsf = wl, *lst = wl + Kp;
+            int *lif = reinterpret_cast<int *>(wl + 2 * Kp), *lit = lif + Kp;
+            float *sm = wl + 4 * Kp;
+            const __amdgpu_buffer_rsrc_t s_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_scores, 0, tl.planes * k * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t i_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_inds, 0, tl.planes * k * 8, 0x00020000);
+            for (int i = lane; i < k; i += 64) {
+                lsf[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_all, (pf * k + i) * 4, 0, 16));
+                lst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_all, (pt * k + i) * 4, 0, 16));
+                lif[i] = __builtin_amdgcn_raw_buffer_load_b32(i_all, (pf * k + i) * 8, 0, 16);
+                lit[i] = __builtin_amdgcn_raw_buffer_load_b32(i_all, (pt * k + i) * 8, 0, 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (tl.nd == 2) og_collect::limb_rows<2, int>(tl.ca, n, l, lane, lsf, lif, lst, lit, sm);
+            else og_collect::limb_rows<4, int>(tl.ca, n, l, lane, lsf, lif, lst, lit, sm);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
 #undef s_tau
 }
 
@@ -580,74 +779,6 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 //   B) compact the keys >= L (usually just over k of them);
 //   C) rank them by counting and write the k best in order.
 // ---------------------------------------------------------------------------------------
-// One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
-// this the same number of times: it contains workgroup barriers).  `all` / `flt`: n_all = nbands * k keys each, in LDS;
-// `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
-template <bool NMS_MODE, bool FUSED, class Emit>
-__device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, const int *__restrict__ gc, uint64_t *all,
-                                            uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
-                                            const float *__restrict__ p, int H, int W, int k, int nbands, int t_sub, Emit &&emit)
-{
-    const int n_all = nbands * k, lane = tid & 63;
-    // keys and band counts are fetched together (one memory round trip), masked afterwards
-    for (int i = tid; i < n_all; i += nthr) {
-        const uint64_t key = gk[i];
-        const int c = gc[i / k];
-        all[i] = (i % k < c) ? key : 0ull;
-    }
-    if (tid == 0) { *s_bound = 0ull; *s_nf = 0; }
-    __syncthreads();
-    // A) k-th largest of the subset {first t_sub keys of each band}
-    const int n_sub = nbands * t_sub;
-    for (int i = tid; i < n_sub; i += nthr) flt[i] = all[(i / t_sub) * k + i % t_sub];
-    __syncthreads();
-    for (int i = tid; i < n_sub; i += nthr) {
-        const uint64_t mine = flt[i];
-        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) *s_bound = mine;
-    }
-    __syncthreads();
-    const uint64_t bound = *s_bound;
-    // B) keys >= bound (order does not matter: ranks are recomputed)
-    for (int i = tid; i < n_all; i += nthr) {
-        const uint64_t key = all[i];
-        if (key != 0ull && key >= bound) flt[atomicAdd(s_nf, 1)] = key;
-    }
-    __syncthreads();
-    const int nf = *s_nf;
-    // C) rank and emit
-    for (int i = tid; i < nf; i += nthr) {
-        const uint64_t mine = flt[i];
-        const int rank = og_count_greater(flt, nf, mine);
-        if (rank < k) emit(rank, og_key_value(mine), (long)og_key_index(mine));
-    }
-    int t = min(nf, k);
-    if (NMS_MODE && t < k && tid < 64) {
-        // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
-        // zero (ties at 0.0 broken by index, like every other tie)
-        auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
-        const long hw = (long)H * W;
-        for (long base = 0; base < hw && t < k; base += 64) {
-            const long i = base + lane;
-            bool zero = false;
-            if (i < hw) {
-                const int y = (int)(i / W), x = (int)(i % W);
-                const float v = px(y, x);
-                float m = (y == 0 || x == 0 || y == H - 1 || x == W - 1) ? 0.f : -INFINITY;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int yy = y + dy, xx = x + dx;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, px(yy, xx));
-                    }
-                zero = !(v == m && v != 0.f);
-            }
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(zero);
-            const int slot = t + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (zero && slot < k) emit(slot, 0.f, i);
-            t += __builtin_popcountll(mask);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // merge kernel: one workgroup per plane selects the plane's top-k from the sorted band lists.
 //   A) a lower bound L on the k-th best: the k-th largest among the first `t` keys of every
@@ -727,6 +858,13 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restri
     if (threadIdx.x < 64) og_collect::limb_rows<ND, int>(a, n, l, threadIdx.x, ls, li, ls + Kp, li + Kp, sm);
 }
 
+// dynamic LDS the tail of band_topk_kernel<..., TAIL> needs (see its carve-up), for a workgroup of `waves` waves
+size_t band_tail_lds_bytes(int nbands, int k, int L, int waves)
+{
+    const size_t n_all = (size_t)nbands * k, Kp = (size_t)((k + 3) & ~3);
+    return (((4 * n_all + 2 + 2 + L + 1 + 3) & ~(size_t)3) + (size_t)waves * 8 * Kp) * 4;
+}
+
 struct Plan {
     int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;
     size_t keys_off, cnt_off, hist_off, magic_off, bytes;
@@ -768,10 +906,15 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     return true;
 }
 
-struct Pairing {   // og_generate_limbs_f32: the merge launch also pairs the limbs
+struct Pairing {   // og_generate_limbs_f32: the limbs are paired by the band launch itself, or by the merge launch
     og_collect::Args a;
     int nd, N;
+    int *tickets;          // zero-filled ticket area for the in-launch tail (or nullptr) and its size
+    size_t ticket_bytes;
+    int tail_in_band;
 };
+inline int pair_N(const Pairing *p) { return p ? p->N : 0; }
+inline int pair_L(const Pairing *p) { return p ? p->a.L : 0; }
 
 template <bool NMS_MODE, bool FUSED = false>
 int run_topk(const float *in, long planes, int H, int W, int k, float *out_scores, int64_t *out_inds,
@@ -805,16 +948,38 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
     const dim3 block(64 * (p.nwaves + (helper & 1)));
     const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
+    const TailArgs no_tail{};
+    if constexpr (NMS_MODE && !FUSED) {
+        // og_generate_limbs_f32 with OG_LIMBS_TAIL_IN_BAND: merge + pairing inside the band launch, by last arrivers
+        const int tail_in_band = pair ? pair->tail_in_band : 0;
+        const int waves = p.nwaves + (helper & 1);
+        const size_t tlds = pair ? band_tail_lds_bytes(p.nbands, k, pair->a.L, waves) : 0;
+        const size_t n_tickets = (size_t)planes + (size_t)pair_N(pair) * pair_L(pair) + 1;
+        if (pair && pair->tickets && tail_in_band && p.vec == 4 && tlds <= 64 * 1024 && n_tickets * sizeof(int) <= pair->ticket_bytes &&
+            (size_t)planes * k < (1u << 27)) {
+            TailArgs tl;
+            tl.tickets = pair->tickets;
+            tl.out_scores = out_scores; tl.out_inds = out_inds;
+            tl.ca = pair->a; tl.nd = pair->nd; tl.t_sub = p.t_sub; tl.planes = (int)planes;
+            hipLaunchKernelGGL((band_topk_kernel<4, true, kPrefetch, kBandAbl, false, true>), dim3(padded), block, lds > tlds ? lds : tlds,
+                               stream, in, keys, cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips,
+                               (int)total, padded, helper, tl);
+            OG_LAUNCH_CHECK(name);
+            return 1;   // paired
+        }
+    }
     if (FUSED)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
                            cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded,
-                           helper);
+                           helper, no_tail);
     else if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
+                           no_tail);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper);
+                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
+                           no_tail);
     OG_LAUNCH_CHECK(name);
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
@@ -957,8 +1122,10 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
         int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
         // two launches: the merge launch pairs the limbs as well (OG_K1_PAIR_IN_MERGE=0: merge, then the collect kernel)
         static const int pair_in_merge = env_int("OG_K1_PAIR_IN_MERGE", 1);
-        const Pairing pr{ca, vector_nd, N};
-        const bool can_pair = pair_in_merge && (long)H * W < (1l << 31) && k <= 2048;
+        // the ticket area at the head of the workspace (all zero between calls) serves the in-launch tail as well
+        const Pairing pr{ca, vector_nd, N, reinterpret_cast<int *>(workspace), (size_t)kP2TicketBytes - 4096,
+                         (flags & OG_LIMBS_TAIL_IN_BAND) != 0};
+        const bool can_pair = (pair_in_merge || pr.tail_in_band) && (long)H * W < (1l << 31) && k <= 2048;
         const int rc = run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
                                       can_pair ? &pr : nullptr);
         if (rc < 0 || rc == 1) return rc < 0 ? rc : OG_OK;

@@ -87,6 +87,11 @@ def test_single_launch_matches_oracle_and_three_launch(dev, n, size, k):
     assert torch.equal(l0, limbs) and torch.equal(s0, sc) and torch.equal(i0, ix)
     l0_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False, single=False)
     assert torch.equal(l0_only, limbs)
+    l2, s2, i2, w2 = run_single(t_hr, t_off, k, dev, single=_lib.OG_LIMBS_TAIL_IN_BAND)   # merge + pairing by last arrivers of the band launch
+    assert torch.equal(l2, limbs) and torch.equal(s2, sc) and torch.equal(i2, ix)
+    assert int(w2[:61440].view(torch.int32).abs().sum()) == 0, "tickets not returned to zero"
+    l2_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False, single=_lib.OG_LIMBS_TAIL_IN_BAND)
+    assert torch.equal(l2_only, limbs)
 
 
 def test_degenerate_planes(dev):
@@ -106,6 +111,9 @@ def test_degenerate_planes(dev):
     assert (sc.cpu().numpy() == rs).all() and (ix.cpu().numpy() == ri).all()
     l3, _, _ = run_three(t_hr, t_off, k, dev)
     assert torch.equal(l3, limbs)
+    for flags in (0, _lib.OG_LIMBS_TAIL_IN_BAND):   # the zero-filler rule in the merge kernel / in the band launch's tail
+        lf, sf, xf, _ = run_single(t_hr, t_off, k, dev, single=flags)
+        assert torch.equal(lf, limbs) and torch.equal(sf, sc) and torch.equal(xf, ix)
 
 
 def test_workspace_reuse_across_shapes_and_fallback(dev):
@@ -124,7 +132,8 @@ def test_workspace_reuse_across_shapes_and_fallback(dev):
             hr = synth.noise_batch(700 + j, (n, 17, h, w)) - 0.3
             off = synth.noise_batch(800 + j, (n, 38, h, w)) * 5
             t_hr, t_off, off_lr = torch.from_numpy(hr).to(dev), torch.from_numpy(off).to(dev), False
-        limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev, ws=ws, off_lowres=off_lr, single=j != 4)   # (flags 0 in between)
+        limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev, ws=ws, off_lowres=off_lr,
+                                      single=(1, 2, 1, 2, 0, 2, 1)[j])   # all three forms share the workspace
         rs, ri, _, _ = oracle.nms_topk(hr, k)
         assert (sc.cpu().numpy() == rs).all() and (ix.cpu().numpy() == ri).all(), (j, n, h, w, k)
         ref = oracle.collect_limbs(rs, ri, off, off_lr, (h, w), SK, 0.04, 0.5)

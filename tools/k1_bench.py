@@ -83,6 +83,11 @@ def main():
                                                  _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
                                                  _lib.ptr(limbs2), 0, _lib.ptr(ws1), ws1.numel(), sp), lib)
 
+        def inband(i):   # flags 2: merge + pairing by last arrivers inside the band launch
+            _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[i % a.rotate]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
+                                                 _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
+                                                 _lib.ptr(limbs2), 2, _lib.ptr(ws1), ws1.numel(), sp), lib)
+
         def three(i):
             _lib.check(lib.og_nms_topk_f32(_lib.ptr(hrs[i % a.rotate]), n * c, h, w, k, _lib.ptr(sc), _lib.ptr(ix), _lib.ptr(ws3),
                                            ws3.numel(), sp), lib)
@@ -96,6 +101,9 @@ def main():
             two(i)
             torch.cuda.synchronize()
             ok = ok and torch.equal(limbs1, limbs3) and torch.equal(limbs2, limbs3) and torch.equal(sc2, sc) and torch.equal(ix2, ix)
+            inband(i)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(limbs2, limbs3) and torch.equal(sc2, sc) and torch.equal(ix2, ix)
         tick = int(ws1[:61440].view(torch.int32).abs().sum())
 
         def timed(fn, pre=None):
@@ -117,8 +125,8 @@ def main():
             t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
             return float(np.median(t)), float(t.min())
 
-        res = {'single cold': timed(single), 'two cold': timed(two), 'three cold': timed(three),
-               'single after K1a': timed(single, k1a), 'two after K1a': timed(two, k1a), 'three after K1a': timed(three, k1a)}
+        res = {'single cold': timed(single), 'two cold': timed(two), 'in-band cold': timed(inband), 'three cold': timed(three),
+               'single after K1a': timed(single, k1a), 'two after K1a': timed(two, k1a), 'in-band after K1a': timed(inband, k1a), 'three after K1a': timed(three, k1a)}
         if a.burst:
             ga = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
             gb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
