@@ -186,3 +186,27 @@ def test_errors(dev):
     rc = lib.og_generate_limbs_f32(_lib.ptr(t), _lib.ptr(o), 1, 3, None, 0, None, 0, 1, 17, 64, 64, _lib.ptr(jf), _lib.ptr(jt),
                                    19, 32, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs), 1, _lib.ptr(ws), ws.numel(), None)
     assert rc == _lib.OG_EUNSUPPORTED
+
+
+def test_random_shapes_all_forms_agree(dev):
+    """Random (N, H, W, k) incl. degenerate planes: flags 0 (band + merge-and-pair), SINGLE_LAUNCH and TAIL_IN_BAND against the
+    separate entry points, bit for bit, tickets back at zero."""
+    rng = np.random.default_rng(7)
+    done = 0
+    for it in range(40):
+        n, h, w = int(rng.integers(1, 7)), int(rng.integers(4, 80)) * 4, int(rng.integers(4, 80)) * 4
+        k = int(rng.choice([1, 3, 8, 17, 32, 40, 64, 100]))
+        if h * w < k or 2 * (h + w) - 4 < k:
+            continue
+        hm = (synth.noise_batch(1000 + it, (n, 17, h, w)) - rng.uniform(0.2, 0.6)).astype(np.float32)
+        if it % 5 == 0:
+            hm[:, ::3] = 0.0
+        off = (synth.noise_batch(2000 + it, (n, 38, h // 4, w // 4)) * 6).astype(np.float32)
+        t_hr, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+        l3, s3, i3 = run_three(t_hr, t_off, k, dev)
+        for flags in (0, _lib.OG_LIMBS_SINGLE_LAUNCH, _lib.OG_LIMBS_TAIL_IN_BAND):
+            l, s, i, ws = run_single(t_hr, t_off, k, dev, single=flags)
+            assert torch.equal(l, l3) and torch.equal(s, s3) and torch.equal(i, i3), (it, n, h, w, k, flags)
+            assert int(ws[:61440].view(torch.int32).abs().sum()) == 0, (it, flags)
+        done += 1
+    assert done >= 30
