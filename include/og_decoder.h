@@ -217,6 +217,12 @@ int og_center_pad_normalize_u8(const unsigned char *img, int h, int w, int targe
  * oracle/og_oracle.c:ogo_resize_cubic_u8 -- parity with cv2 itself is unpinned (third-party, absent from the build). */
 int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int new_h, int new_w, void *stream);
 
+/* GT encoder input: the full-resolution uint8 mask_miss (N,h,w), 0 / 255, to the boolean mask at output
+ * resolution -- cv2.resize(fx = fy = 1 / stride, INTER_CUBIC) / 255 > 0.7, encoder/heatmap.py:56-60, encoder/offset.py:46-50.
+ * out: (N, round(h / stride), round(w / stride)) bytes 0 / 1.  Same published 8-bit algorithm as og_resize_cubic_u8
+ * (pinned to oracle/og_oracle.c:ogo_shrink_mask_miss_u8; parity with cv2 itself unpinned). */
+int og_shrink_mask_miss_u8(const unsigned char *mask, int N, int h, int w, int stride, unsigned char *out, void *stream);
+
 /* The whole input chain of evaluate.py:150-168 in one pass: rescale to (new_h,new_w) as above, pad to (target_h,target_w)
  * with the fill colour -- corner_pad 0: CenterPad (transforms/pad.py:35-62, the --long-edge chain), 1: RightDownPad
  * (transforms/pad.py:70-118, the --fixed-height chain: left = top = 0) --, ToTensor, Normalize -> out fp32

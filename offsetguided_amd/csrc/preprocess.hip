@@ -74,6 +74,30 @@ resize_cubic_kernel(const unsigned char *__restrict__ src, int h, int w, unsigne
     for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (unsigned char)v[c];
 }
 
+// encoder/heatmap.py:56-60, encoder/offset.py:46-50: one channel of the same resize, / 255 > 0.7 (<=> value >= 179)
+__global__ void __launch_bounds__(256)
+shrink_mask_kernel(const unsigned char *__restrict__ mask, int N, int h, int w, unsigned char *__restrict__ out, int nh, int nw,
+                   double sy, double sx)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * nh * nw) return;
+    const int n = (int)(i / ((long)nh * nw)), r = (int)(i % ((long)nh * nw));
+    const int dy = r / nw, dx = r % nw;
+    const unsigned char *src = mask + (size_t)n * h * w;
+    const Taps ty = cubic_taps(dy, sy), tx = cubic_taps(dx, sx);
+    int acc = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const unsigned char *row = src + (size_t)min(max(ty.i0 + rr, 0), h - 1) * w;
+        int hs = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hs += (int)row[min(max(tx.i0 + k, 0), w - 1)] * tx.t[k];
+        acc += hs * ty.t[rr];
+    }
+    const int v = min(max((acc + (1 << 21)) >> 22, 0), 255);
+    out[i] = (float)v / 255.f > 0.7f ? 1 : 0;
+}
+
 struct PrepArgs {
     float mean[3], stdv[3], fill[3];
 };
@@ -108,6 +132,21 @@ OG_API int og_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned c
     const long total = (long)new_h * new_w;
     hipLaunchKernelGGL(resize_cubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, h, w, dst,
                        new_h, new_w, (double)h / new_h, (double)w / new_w);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_shrink_mask_miss_u8(const unsigned char *mask, int N, int h, int w, int stride, unsigned char *out, void *stream)
+{
+    const char *name = "og_shrink_mask_miss_u8";
+    OG_REQUIRE(mask && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && h > 0 && w > 0 && stride > 0 && (long)N * h * w < (1l << 30), OG_EINVAL, "%s: bad shape", name);
+    // cv2.resize(dsize = (0, 0), fx = fy = 1 / stride): dsize = round(size * f), coordinates scaled by 1 / f = stride
+    const int nh = (int)lrint((double)h / stride), nw = (int)lrint((double)w / stride);
+    OG_REQUIRE(nh > 0 && nw > 0, OG_EINVAL, "%s: stride larger than the mask", name);
+    const long total = (long)N * nh * nw;
+    hipLaunchKernelGGL(shrink_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, N, h, w, out,
+                       nh, nw, (double)stride, (double)stride);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

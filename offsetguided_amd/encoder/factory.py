@@ -6,9 +6,10 @@ The reference encodes one image at a time with numpy inside dataloader workers; 
 training device.  `enc(anns, meta, mask_miss)` keeps the per-image call of the reference (numpy in, tensors out);
 `enc.encode_batch(joints, n_persons, mask_miss)` is the batched device form.
 
-mask_miss: the reference shrinks the full-resolution uint8 mask with cv2.resize(INTER_CUBIC) (heatmap.py:58-62), which
-cannot be pinned here (no cv2 in the image); these encoders take the mask at OUTPUT resolution, already boolean
-(True = labelled), or None for "everything labelled"."""
+mask_miss: the reference's input, the full-resolution uint8 mask (0 / 255), is shrunk on the device like its
+cv2.resize(fx = 1 / stride, INTER_CUBIC) / 255 > 0.7 (heatmap.py:56-60; OpenCV's published 8-bit algorithm, parity with cv2
+itself unpinned: no cv2 in the image); a boolean mask at OUTPUT resolution (True = labelled) passes through; None =
+"everything labelled"."""
 import logging
 import re
 
@@ -37,14 +38,25 @@ def _batch_joints(joints, n_persons, device):
     return joints, n_persons
 
 
-def _mask(mask_miss, n, h, w, device):
+def _mask(mask_miss, n, h, w, device, stride):
+    """mask_miss -> bool (n,1,h,w) on the device.  A boolean mask at output resolution passes through; the reference's input,
+    the full-resolution uint8 mask (0 / 255), is shrunk on the device like cv2.resize(fx = 1 / stride, INTER_CUBIC) / 255 >
+    0.7 (encoder/heatmap.py:56-60; og_shrink_mask_miss_u8, parity with cv2 unpinned)."""
     if mask_miss is None:
         return torch.ones((n, 1, h, w), dtype=torch.bool, device=device)
     mask = torch.as_tensor(mask_miss)
-    if mask.dtype != torch.bool or tuple(mask.shape[-2:]) != (h, w):
-        raise NotImplementedError('mask_miss must be boolean at output resolution: the reference\'s cv2 INTER_CUBIC '
-                                  'shrink of the full-resolution uint8 mask is not reproduced')
-    return mask.reshape(n, 1, h, w).to(device)
+    if mask.dtype == torch.bool and tuple(mask.shape[-2:]) == (h, w):
+        return mask.reshape(n, 1, h, w).to(device)
+    if mask.dtype != torch.uint8 or (round(mask.shape[-2] / stride), round(mask.shape[-1] / stride)) != (h, w):
+        raise ValueError(f'mask_miss: bool at output resolution ({h}, {w}) or uint8 at input resolution, got {mask.dtype} '
+                         f'{tuple(mask.shape)}')
+    from .. import _lib
+    lib = _lib.load()
+    full = mask.reshape(n, mask.shape[-2], mask.shape[-1]).contiguous().to(device)
+    out = torch.empty((n, 1, h, w), dtype=torch.uint8, device=device)
+    _lib.check(lib.og_shrink_mask_miss_u8(_lib.ptr(full), n, full.shape[1], full.shape[2], int(stride), _lib.ptr(out),
+                                          _lib.stream_ptr(device)), lib)
+    return out.bool()
 
 
 class _Encoder:
@@ -99,7 +111,7 @@ class HeatMaps(_Encoder):
                 _lib.ptr(joints), _lib.ptr(n_persons) if n_persons is not None else None, n, p, n_kp,
                 self.input_size[0], self.input_size[1], int(self.stride), int(self.fill_jitter_size), _lib.ptr(jit),
                 _lib.stream_ptr(dev)), lib)
-        return hm, (bg if bg is not None else empty), jit, _mask(mask_miss, n, h, w, dev)
+        return hm, (bg if bg is not None else empty), jit, _mask(mask_miss, n, h, w, dev, self.stride)
 
 
 class OffsetMaps(_Encoder):
@@ -129,7 +141,7 @@ class OffsetMaps(_Encoder):
             _lib.ptr(_lib.int_table([b for _, b in self.skeleton], dev)), n_limbs,
             self.input_size[0], self.input_size[1], int(self.stride), int(self.fill_scale_size), float(self.min_jscale),
             _lib.ptr(sig), _lib.ptr(off), _lib.ptr(sc) if sc is not None else None, _lib.ptr(ps), _lib.stream_ptr(dev)), lib)
-        return off, (sc if sc is not None else torch.tensor([], device=dev)), ps, _mask(mask_miss, n, h, w, dev)
+        return off, (sc if sc is not None else torch.tensor([], device=dev)), ps, _mask(mask_miss, n, h, w, dev, self.stride)
 
 
 _sigma_cache = {}

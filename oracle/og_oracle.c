@@ -809,7 +809,7 @@ static void ogo_cubic_taps(float x, short *t)
 
 static int ogo_clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
-OGO_API void ogo_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int nh, int nw)
+static void ogo_resize_cubic_u8_ch(const unsigned char *src, int h, int w, unsigned char *dst, int nh, int nw, int ch)
 {
     const double sx = (double)w / nw, sy = (double)h / nh;
     for (int dy = 0; dy < nh; ++dy) {
@@ -822,17 +822,31 @@ OGO_API void ogo_resize_cubic_u8(const unsigned char *src, int h, int w, unsigne
             const int x0 = (int)floorf(fx);
             short ax[4];
             ogo_cubic_taps(fx - (float)x0, ax);
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < ch; ++c) {
                 int acc = 0;
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned char *row = src + (size_t)ogo_clampi(y0 - 1 + r, 0, h - 1) * w * 3;
+                    const unsigned char *row = src + (size_t)ogo_clampi(y0 - 1 + r, 0, h - 1) * w * ch;
                     int hs = 0;
-                    for (int k = 0; k < 4; ++k) hs += row[ogo_clampi(x0 - 1 + k, 0, w - 1) * 3 + c] * ax[k];
+                    for (int k = 0; k < 4; ++k) hs += row[ogo_clampi(x0 - 1 + k, 0, w - 1) * ch + c] * ax[k];
                     acc += hs * by[r];
                 }
                 const int v = (acc + (1 << 21)) >> 22;
-                dst[((size_t)dy * nw + dx) * 3 + c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+                dst[((size_t)dy * nw + dx) * ch + c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
             }
         }
     }
+}
+
+OGO_API void ogo_resize_cubic_u8(const unsigned char *src, int h, int w, unsigned char *dst, int nh, int nw)
+{
+    ogo_resize_cubic_u8_ch(src, h, w, dst, nh, nw, 3);
+}
+
+/* encoder/heatmap.py:56-60, encoder/offset.py:46-50: the full-resolution uint8 mask_miss (h, w), 0 / 255, shrunk by
+ * cv2.resize(fx = fy = 1 / stride, INTER_CUBIC), / 255, > 0.7 -> bool (h / stride, w / stride).  float32(v) / 255 > 0.7
+ * <=> v >= 179 for integer v.  Same published 8-bit algorithm as above (parity with cv2 itself unpinned). */
+OGO_API void ogo_shrink_mask_miss_u8(const unsigned char *mask, int h, int w, unsigned char *out, int nh, int nw)
+{
+    ogo_resize_cubic_u8_ch(mask, h, w, out, nh, nw, 1);
+    for (long i = 0; i < (long)nh * nw; ++i) out[i] = (float)out[i] / 255.f > 0.7f ? 1 : 0;
 }

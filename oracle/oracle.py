@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "libog_oracle.so")
 
 __all__ = [
     "build", "bicubic4", "bilinear4", "hmp_nms", "topk", "nms_topk", "collect_limbs",
-    "greedy_group", "group_stats", "resize_cubic_u8", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "encode_jitter", "decode",
+    "greedy_group", "group_stats", "resize_cubic_u8", "shrink_mask_miss_u8", "flip_merge", "flip_cat", "encode_heatmaps", "encode_offsets", "encode_jitter", "decode",
 ]
 
 _lib = None
@@ -69,6 +69,7 @@ def lib():
                                      _I32, _I32, _I32, C.c_int, _F, _F]
         L.ogo_resize_cubic_u8.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int,
                                           np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int]
+        L.ogo_shrink_mask_miss_u8.argtypes = L.ogo_resize_cubic_u8.argtypes
         L.ogo_group_stats.argtypes = [np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), C.c_int]
         _lib = L
     return _lib
@@ -246,6 +247,16 @@ def resize_cubic_u8(img, new_h, new_w):
     out = np.empty((new_h, new_w, 3), np.uint8)
     lib().ogo_resize_cubic_u8(img, img.shape[0], img.shape[1], out, new_h, new_w)
     return out
+
+
+def shrink_mask_miss_u8(mask, stride):
+    """encoder/heatmap.py:56-60: (h, w) uint8 mask_miss -> bool (h // stride, w // stride) = cv2.resize(fx = 1 / stride, INTER_CUBIC)
+    / 255 > 0.7 (PARITY UNPINNED against cv2, like resize_cubic_u8)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    nh, nw = int(round(mask.shape[0] / stride)), int(round(mask.shape[1] / stride))
+    out = np.empty((nh, nw), np.uint8)
+    lib().ogo_shrink_mask_miss_u8(mask, mask.shape[0], mask.shape[1], out, nh, nw)
+    return out.astype(bool)
 
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,

@@ -89,5 +89,11 @@ def test_gpu_encoder_matches_reference_golden(case):
     # the per-image call of the reference API
     one = hm_enc(j, {'width_height': [size, size], 'joint_num': 17}, None)
     assert heatmaps_match(one[0].cpu().numpy(), g[f"{case}_hm"]) and one[3].shape == (1, size // 4, size // 4)
-    with pytest.raises(NotImplementedError):
-        hm_enc.encode_batch(batch, n_persons, np.zeros((3, size, size), np.uint8))
+    # the reference's mask_miss input: uint8 at input resolution, shrunk on the device (encoder/heatmap.py:56-60)
+    full = np.full((3, size, size), 255, np.uint8)
+    full[1, : size // 2] = 0
+    m = hm_enc.encode_batch(batch, n_persons, full)[3].cpu().numpy()
+    assert m.shape == (3, 1, size // 4, size // 4) and m[0].all() and m[2].all()
+    assert not m[1, 0, : size // 8 - 1].any() and m[1, 0, size // 8 + 1:].all()
+    with pytest.raises(ValueError):
+        hm_enc.encode_batch(batch, n_persons, np.zeros((3, size, size), np.float32))

@@ -122,3 +122,42 @@ def test_resize_and_fused_chain_bit_exact_vs_restatement():
         assert out.shape == (4, 3, 640, 640) and len(metas) == 4
         single, _ = pre([images[2]])
         assert torch.equal(out[2], single[0])
+
+
+def _mask_cases():
+    rng = np.random.default_rng(5)
+    m = np.full((3, 128, 192), 255, np.uint8)
+    m[0, 20:60, 30:100] = 0                                   # a box
+    yy, xx = np.mgrid[:128, :192]
+    m[1][(yy - 64) ** 2 + (xx - 90) ** 2 < 40 ** 2] = 0      # a disc
+    m[2] = (rng.random((128, 192)) > 0.3).astype(np.uint8) * 255   # salt and pepper: the cubic taps overshoot
+    return m
+
+
+def test_oracle_shrink_mask_miss():
+    """ogo_shrink_mask_miss_u8 (encoder/heatmap.py:56-60): far from an edge the mask survives, the result is boolean at 1/4
+    resolution and equals the restated resize + threshold."""
+    import oracle
+    m = _mask_cases()
+    for i in range(3):
+        out = oracle.shrink_mask_miss_u8(m[i], 4)
+        assert out.shape == (32, 48) and out.dtype == bool
+    box = oracle.shrink_mask_miss_u8(m[0], 4)
+    assert box[:4].all() and not box[7:13, 9:23].any()
+    # the one-channel resize agrees with the three-channel one the input chain uses
+    rgb = np.repeat(m[2][:, :, None], 3, 2)
+    assert np.array_equal(oracle.resize_cubic_u8(rgb, 32, 48)[:, :, 0].astype(np.float32) / 255 > 0.7, oracle.shrink_mask_miss_u8(m[2], 4))
+
+
+@pytest.mark.gpu
+def test_shrink_mask_miss_device_matches_oracle():
+    import oracle
+    from offsetguided_amd.encoder import factory as ef
+    m = _mask_cases()
+    got = ef._mask(m, 3, 32, 48, torch.device('cuda:0'), 4).cpu().numpy()[:, 0]
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.shrink_mask_miss_u8(m[i], 4)), i
+    passthrough = ef._mask(got[:, None], 3, 32, 48, torch.device('cuda:0'), 4)
+    assert passthrough.dtype == torch.bool and np.array_equal(passthrough.cpu().numpy()[:, 0], got)
+    with pytest.raises(ValueError):
+        ef._mask(m[:, :100], 3, 32, 48, torch.device('cuda:0'), 4)

@@ -40,6 +40,9 @@ def main():
     torch.cuda.synchronize()
     t = np.median([s.elapsed_time(e) for s, e in evs]) * 1e3
     lib = _lib.load()
+    if not hasattr(lib, 'og_k3_debug_stamps'):
+        print(f'K3 per batch (events): {t:.1f} us  (library without -DOG_K3_STAMPS: no phase breakdown)')
+        return
     buf = (C.c_ulonglong * 16)()
     lib.og_k3_debug_stamps(buf)
     c = np.array(buf[:10], dtype=np.float64)
