@@ -964,7 +964,10 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
         h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
         { static const int policy = getenv("OG_CONV_STORE") ? atoi(getenv("OG_CONV_STORE")) : 0; h.store_policy = policy; }
         h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
-        { static const int items = getenv("OG_CONV_HALO_ITEMS") ? atoi(getenv("OG_CONV_HALO_ITEMS")) : 1; h.items = items < 1 ? 1 : items; }
+        // OG_CONV_HALO_ITEMS = k: k work items per workgroup where the grid stays >= 2 x the CUs; -k: always (tests)
+        static const int items_env = getenv("OG_CONV_HALO_ITEMS") ? atoi(getenv("OG_CONV_HALO_ITEMS")) : 1;
+        h.items = items_env < 0 ? -items_env : items_env < 1 ? 1 : items_env;
+        const bool items_forced = items_env < 0;
         h.stamps = g_stamps;
         h.x_bytes = (int)(M * Cin * 2);
         h.w_bytes = Cout * 9 * Cin * 2;
@@ -977,7 +980,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
             (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<TW_, TH_, WM_>,                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
         const long items_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                        \
-        if (items_ < 1024 * (long)h.items / 2) h.items = 1;   /* several items per workgroup only where the grid stays >= 2 x the CUs */ \
+        if (!items_forced && items_ < 1024 * (long)h.items / 2) h.items = 1;                                      \
         const long blocks_ = (items_ + h.items - 1) / h.items;                                                  \
         hipLaunchKernelGGL((conv3x3_halo_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(512), lds_, st, h); \
     } while (0)

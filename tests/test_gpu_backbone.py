@@ -201,6 +201,20 @@ def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
         assert err <= 6e-3, f'relative error {err}'
 
 
+def test_conv3x3_halo_kernel_several_items_per_workgroup(dev):
+    """OG_CONV_HALO_ITEMS (read once per process): the halo-kernel tests again in a child process with 3 work items per
+    workgroup forced -- cross-item prefetch, two-half epilogue, residual re-initialisation."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, OG_CONV_HALO_ITEMS="-3")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_conv3x3_halo_kernel_matches_torch or test_conv2d_f16_matches_torch"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 32), (2, 64, 96), (1, 128, 64)])
 def test_stem7x7_matches_torch(dev, shape):
     """og_stem7x7_bf16 (fp32 NCHW in, conv 7x7 s2 p3 + bias + ReLU, bf16 NHWC out) vs an fp32 torch convolution of the
