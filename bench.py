@@ -64,6 +64,10 @@ def parse():
                     help='engine arithmetic: bf16 (default) or f16 (the reference evaluates in fp16 through apex O2); same MFMA rate')
     ap.add_argument('--no-extras', action='store_true',
                     help='headline region only: skip the decoder-only / backbone-only / conv / HBM-cold / flip measurements')
+    ap.add_argument('--allow-diagnostic', action='store_true',
+                    help='run although a timing-only switch that produces WRONG RESULTS is set (OG_ENGINE_WHATIF, OG_DECODER_LIB, '
+                         'OG_BENCH_FAIL_RANK): the JSON line then carries "diagnostic": true and is not a measurement')
+    ap.add_argument('--no-f16', action='store_true', help='skip the fp16-engine figure (the reference\'s apex-O2 arithmetic)')
     ap.add_argument('--dry-run', action='store_true',
                     help='control plane only (CPU test aid): the ranks rendezvous over gloo, run the barrier / MAX-over-ranks '
                          'protocol and rank 0 prints the JSON skeleton with value null; no kernel runs')
@@ -97,6 +101,38 @@ def bench_init(model, seed):
                 m.weight.data.mul_(1e-4)
 
 
+DIAGNOSTIC_SWITCHES = ('OG_ENGINE_WHATIF', 'OG_DECODER_LIB')   # wrong-results / foreign-library switches of the product path
+
+
+def knobs():
+    """Every environment switch that can change what this process measures: all OG_*, HIP_*, HSA_*, MIOPEN_* variables and
+    GPU_MAX_HW_QUEUES, as set when the line is printed (bench.py's own setdefaults included)."""
+    pre = ('OG_', 'HIP_', 'HSA_', 'MIOPEN_')
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(pre) or k in ('GPU_MAX_HW_QUEUES', 'PYTORCH_ROCM_ARCH')}
+
+
+def diagnostic_switches():
+    return [k for k in DIAGNOSTIC_SWITCHES if os.environ.get(k, '')]
+
+
+def k1_traffic(kernels):
+    """HBM bytes per K1 launch from the PMC passes of profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    tools/pmc_traffic.py), or None: the newest tracked file is used only if it lists EVERY kernel `roofline.kernel` names and
+    its total is the sum of exactly those kernels."""
+    import glob
+    for tfile in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_k1_traffic.json')), reverse=True):
+        try:
+            t = json.load(open(tfile))
+            per = t['per_kernel']
+            total = sum(per[k]['read'] + per[k]['write'] for k in kernels)
+        except (KeyError, ValueError, OSError):
+            return None, None          # the newest file does not describe these kernels: report nothing rather than a stale figure
+        if abs(total - t.get('hbm_bytes_per_launch', -1)) > 1e-6 * total:
+            return None, None
+        return int(t['hbm_bytes_per_launch']), os.path.relpath(tfile, ROOT)
+    return None, None
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -114,8 +150,11 @@ def launch_ranks(a):
     have = torch.cuda.device_count()
     if a.gpus > have and not (share or a.dry_run):
         sys.exit(f'bench.py: --gpus {a.gpus} but only {have} HIP device(s) are visible')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    # --max-restarts 0 + a short monitor interval: a rank that dies (engine build failure, missing library) takes the job
+    # down with a non-zero exit code instead of leaving its peers at the barrier
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--max-restarts=0',
+           '--monitor-interval=1', '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this host driver
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
@@ -125,14 +164,18 @@ def launch_ranks(a):
 def dry_run(a, sharding):
     """The N-rank control plane without a GPU: same rendezvous, barriers and MAX-reduce as the real run."""
     rank, _, world = sharding.init(backend='gloo')
+    if os.environ.get('OG_BENCH_FAIL_RANK') == str(rank):   # test aid: a rank that dies before the first barrier
+        sys.exit(f'bench.py: rank {rank} told to fail (OG_BENCH_FAIL_RANK)')
     sharding.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    group = sharding.describe_group(None)
     if rank == 0:
         print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps,
-                          'warmup': a.warmup, 'ms_per_step': None, 'dry_run': True, 'elapsed_s': round(elapsed, 4)}))
+                          'warmup': a.warmup, 'ms_per_step': None, 'dry_run': True, 'elapsed_s': round(elapsed, 4),
+                          'rccl': group, 'knobs': knobs(), **({'diagnostic': True} if diagnostic_switches() else {})}))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -145,6 +188,11 @@ def main():
         if 'RANK' in os.environ or 'LOCAL_RANK' in os.environ:   # under a launcher whose world size disagrees with --gpus
             sys.exit(f'bench.py: --gpus {a.gpus} does not match WORLD_SIZE={env_world} of the launcher')
         sys.exit(launch_ranks(a))
+    diag = diagnostic_switches()
+    if diag and not a.allow_diagnostic:
+        sys.exit('bench.py: ' + ', '.join(f'{k}={os.environ[k]}' for k in diag) + ' is set: that switch makes the product path '
+                 'return wrong results or load a foreign library; a line measured with it is not a benchmark.  Unset it, or pass '
+                 '--allow-diagnostic (the line is then marked "diagnostic": true)')
     from offsetguided_amd import sharding
     if a.dry_run:
         return dry_run(a, sharding)
@@ -174,10 +222,11 @@ def main():
     class Pipeline:
         """One configuration of the hot path: engine (HIP graph) + decoder + resident synthetic inputs."""
 
-        def __init__(self, flip, inflight=1):
+        def __init__(self, flip, inflight=1, dtype=None):
             self.flip = flip
             self.nb = a.batch * (2 if flip else 1)
-            self.engines = [models.InferenceEngine(model, self.nb, a.size, a.size, dtype=torch.float16 if a.dtype == 'f16' else torch.bfloat16, device=dev,
+            dtype = dtype or a.dtype
+            self.engines = [models.InferenceEngine(model, self.nb, a.size, a.size, dtype=torch.float16 if dtype == 'f16' else torch.bfloat16, device=dev,
                                                    use_graph=not a.no_graph) for _ in range(inflight)]
             self.procs = [decoder.decoder_factory(margs) for _ in range(inflight)]
             self.engine, self.proc = self.engines[0], self.procs[0]
@@ -328,16 +377,29 @@ def main():
                                  'K0 flip merge, full decoder (BASELINE configs[2])'}
         del fpipe
 
+    # ---- the reference's arithmetic (fp16 through apex O2, evaluate.py:92,198-201) timed in the same process, same steps ----
+    f16_line = None
+    if not a.no_extras and not a.no_f16 and not a.flip and a.inflight == 1 and a.dtype != 'f16':
+        torch.cuda.empty_cache()
+        hpipe = Pipeline(False, dtype='f16')
+        _, _, h_elapsed, h_stage = hpipe.timed_region(a.steps, a.warmup)
+        h_bb = timed(lambda i: hpipe.engine.forward_raw(hpipe.images[i % n_rot]), 10)
+        f16_line = {'value': round(a.batch * a.steps * world / h_elapsed, 2), 'unit': 'images/sec',
+                    'ms_per_step': round(h_elapsed / a.steps * 1e3, 3), 'backbone_ms_per_batch': round(h_bb, 3),
+                    'k1_generate_limbs_us': round(float(np.mean(h_stage['k1_generate_limbs'])), 2),
+                    'workload': 'the headline workload with the fp16 engine (og_*_f16 kernels: same MFMA rate, 3 more mantissa '
+                                'bits; the reference evaluates in fp16)'}
+        del hpipe
+
+    group = sharding.describe_group(dev)
     if rank == 0:
         k1 = float(np.mean(stage_us['k1_generate_limbs']))
         k1_bytes = a.batch * K1_BYTES_PER_IMAGE * (a.size * a.size) / (640 * 640)
         achieved = k1_bytes / (k1 * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, profiles/README.md): only a figure
         # measured on THIS round's kernels is reported
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02e_k1_traffic.json')
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+        k1_kernels = ('band_topk_kernel', 'merge_collect_kernel')
+        traffic, traffic_file = k1_traffic(k1_kernels)
         imgs = a.batch * a.steps * world
         line = {
             'metric': METRIC,
@@ -356,9 +418,13 @@ def main():
             'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
                                    'merge_collect_kernel',
                          'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_file,
                          'us_per_launch': round(k1, 2), 'algorithmic_bytes_per_launch': int(k1_bytes)},
+            'rccl': group,
+            'knobs': knobs(),
         }
+        if diag:
+            line['diagnostic'] = True
         if 'k1_cold_us' in extras:
             k1_cold = extras.pop('k1_cold_us')
             line['roofline']['hbm_cold'] = {'us_per_launch': round(k1_cold, 2),
@@ -367,6 +433,8 @@ def main():
         line.update(extras)
         if flip_line is not None:
             line['flip'] = flip_line
+        if f16_line is not None:
+            line['f16'] = f16_line
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a, model, maps, cd)
         print(json.dumps(line))

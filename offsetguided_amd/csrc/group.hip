@@ -99,7 +99,9 @@ __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_anyA, s_anyB, s_anyQ, s_M, s_kept;
+    // any-flags and the per-column counters exist twice, used alternately by successive limb types (`par`): a wave that
+    // is ahead resets the set of the NEXT limb type while laggards may still be reading the current one
+    __shared__ int s_anyA[2], s_anyB[2], s_anyQ[2], s_M, s_kept;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = A.K, L = A.L, nkp = A.nkp, rowf = nkp * 6, mmax = A.mmax, LK = L * K;
     // ---- LDS carve-up (pure pointer arithmetic: an integer round trip for alignment would turn
@@ -118,8 +120,8 @@ greedy_group_kernel(GroupArgs A)
     int *t_dup = (int *)p;       p += LK4;                 //                a better-ranked row has the same to-index
     int *t_urank = (int *)p;     p += LK;                  //                rank among the valid, non-duplicate ones
     int *kk_arr = (int *)p;      p += L;                   // unique rows per limb type
-    int *c_n1 = (int *)p;        p += K;                   // rows with ms==1 per column
-    int *c_n2 = (int *)p;        p += K;                   // rows with ms==2 per column
+    int *c_n1_2 = (int *)p;      p += 2 * K;               // rows with ms==1 per column, two alternating sets
+    int *c_n2_2 = (int *)p;      p += 2 * K;               // rows with ms==2 per column, two alternating sets
     int *c_newcol = (int *)p;    p += K;                   // column of the i-th new row
     int *order = (int *)p;       p += mmax;                // logical position -> physical row
     int *r_a = (int *)p;         p += mmax;                // phase-A column per logical row
@@ -147,8 +149,8 @@ greedy_group_kernel(GroupArgs A)
         t_rank[i] = 0; t_dup[i] = 0; t_urank[i] = 0;
     }
     for (int i = tid; i < L; i += kThreads) kk_arr[i] = 0;
-    for (int i = tid; i < K; i += kThreads) { c_n1[i] = 0; c_n2[i] = 0; }
-    if (tid == 0) { s_M = 0; s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
+    for (int i = tid; i < 2 * K; i += kThreads) { c_n1_2[i] = 0; c_n2_2[i] = 0; }
+    if (tid == 0) { s_M = 0; s_anyA[0] = s_anyA[1] = 0; s_anyB[0] = s_anyB[1] = 0; s_anyQ[0] = s_anyQ[1] = 0; }
     __syncthreads();
     K3_STAMP(7);
     // U2. stable descending rank (:232) and "a better row owns my to-index" (:233-239).  One thread per
@@ -271,14 +273,17 @@ greedy_group_kernel(GroupArgs A)
 
     K3_STAMP(0);
     // ================= serial over limb types =================
-    // invariant at the top: r_a = r_b = r_p = -1, r_d = 0 for rows < M; c_n1 = c_n2 = 0; flags = 0
+    // invariant at the top: r_a = r_b = r_p = -1, r_d = 0 for rows < M; c_n1 = c_n2 = 0 and flags = 0 in the set `par`
     // M_rows (live rows) and P_rows (physical rows ever created) are kept by every wave in registers: they change by
     // wave-uniform arithmetic (new rows) or through s_M behind a barrier (merges)
     int M_rows = 0, P_rows = 0;
     bool overflow = false;
+    int par = 1;
     for (int l = 0; l < L; ++l) {
         const int kk = kk_arr[l];
         if (kk == 0) continue;  // uniform
+        par ^= 1;
+        int *const c_n1 = c_n1_2 + par * K, *const c_n2 = c_n2_2 + par * K;
         const int jf = A.jf[l], jt = A.jt[l];
         const float *lim_l = lim_all + (size_t)l * K * 11;
         const int m0 = M_rows;
@@ -294,8 +299,8 @@ greedy_group_kernel(GroupArgs A)
                 const float lsf = SUBP(ph, jf, 4), lst = SUBP(ph, jt, 4), sc = LIM(c, 8);
                 const int ms = (idf == (int)LIM(c, 9)) + (idt == (int)LIM(c, 10));
                 const bool rep = (int)(sc > lst) | (int)(sc > lsf);
-                if (ms == 2) { atomicAdd(&c_n2[c], 1); if (rep) { r_a[m] = c; s_anyA = 1; } }
-                if (ms == 1) { atomicAdd(&c_n1[c], 1); if (rep) { atomicMax(&r_b[m], c); s_anyB = 1; } }
+                if (ms == 2) { atomicAdd(&c_n2[c], 1); if (rep) { r_a[m] = c; s_anyA[par] = 1; } }
+                if (ms == 1) { atomicAdd(&c_n1[c], 1); if (rep) { atomicMax(&r_b[m], c); s_anyB[par] = 1; } }
             }
             __syncthreads();
             K3_STAMP(1);
@@ -316,8 +321,8 @@ greedy_group_kernel(GroupArgs A)
             }
             __syncthreads();
             K3_STAMP(2);
-            anyA = s_anyA != 0;
-            anyB = s_anyB != 0;
+            anyA = s_anyA[par] != 0;
+            anyB = s_anyB[par] != 0;
             // ---- merge rows sharing exactly two keypoints (:140-161): lanes = row pairs ----
             if (m0 >= 2) {
                 // 16 x 16 tiles of (a, b) over the upper triangle: no index decoding, no divisions (one pair per lane in row-major
@@ -338,11 +343,11 @@ greedy_group_kernel(GroupArgs A)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) cnt += (int)(va[e] == vb[e]) & (int)(va[e] != -1);   // bitwise: no exec-mask branches
                             }
-                            if (cnt == 2) { atomicMax(&r_p[a], b); r_d[b] = 1; s_anyQ = 1; }
+                            if (cnt == 2) { atomicMax(&r_p[a], b); r_d[b] = 1; s_anyQ[par] = 1; }
                         }
                     }
                 __syncthreads();
-                if (s_anyQ) {
+                if (s_anyQ[par]) {
                     // a <- max(a, last partner); partners are deleted rows, which are never written
                     for (int a = tid >> 7; a < m0; a += kThreads >> 7) {   // 128 lanes per row (rowf <= 102)
                         const int f = tid & 127, b = r_p[a];
@@ -413,10 +418,12 @@ greedy_group_kernel(GroupArgs A)
                 sub[(p_first + r) * rowf + jf6] = v;
                 if (jf6 < kIdPitch) ids[(p_first + r) * kIdPitch + jf6] = jf6 == jf ? (int)LIM(c, 9) : (jf6 == jt ? (int)LIM(c, 10) : -1);
             }
-            // re-establish the loop invariant for the next limb type
+            // re-establish the loop invariant for the next limb type.  r_*: last read before a barrier every wave has
+            // passed.  Counters and flags: the OTHER set (dirty since the previous limb type, read by nobody since the
+            // barrier that ended it); the set of this limb type is still being read above by waves that lag behind
             for (int m = tid; m < M; m += kThreads) { r_a[m] = -1; r_b[m] = -1; r_p[m] = -1; r_d[m] = 0; }
-            for (int c = tid; c < kk; c += kThreads) { c_n1[c] = 0; c_n2[c] = 0; }
-            if (tid == 0) { s_anyA = 0; s_anyB = 0; s_anyQ = 0; }
+            for (int c = tid; c < K; c += kThreads) { c_n1_2[(par ^ 1) * K + c] = 0; c_n2_2[(par ^ 1) * K + c] = 0; }
+            if (tid == 0) { s_anyA[par ^ 1] = 0; s_anyB[par ^ 1] = 0; s_anyQ[par ^ 1] = 0; }
         }
         __syncthreads();
         K3_STAMP(5);
@@ -479,7 +486,7 @@ size_t staging_bytes(int L, int K, int mmax)
 {
     const size_t lk = (size_t)L * K;
     return (size_t)mmax * kIdPitch * 4 + (size_t)mmax * 8 +
-           (lk * 11 + lk * 5 + L + (size_t)K * 3 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64 + 6 * 16;
+           (lk * 11 + lk * 5 + L + (size_t)K * 5 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64 + 6 * 16;
 }
 
 }  // namespace

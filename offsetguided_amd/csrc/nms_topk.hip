@@ -981,11 +981,14 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
                            hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
                            no_tail);
     OG_LAUNCH_CHECK(name);
+    // dynamic LDS the merge kernels may ask for without raising the 64 KiB default: their static __shared__ words (bounds,
+    // counters: 24 B) come on top
+    constexpr size_t kDynLdsLimit = 64 * 1024 - 256;
     const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
-    OG_REQUIRE(mlds <= 64 * 1024, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
+    OG_REQUIRE(mlds <= kDynLdsLimit, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
     if constexpr (NMS_MODE && !FUSED) {
         const size_t plds = 2 * mlds + (size_t)((k + 3) & ~3) * 32;
-        if (pair && plds <= 64 * 1024) {
+        if (pair && plds <= kDynLdsLimit) {
             const int NL = pair->N * pair->a.L;
             auto kern = pair->nd == 2 ? merge_collect_kernel<2> : merge_collect_kernel<4>;
             hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, cnts, hist, magic,

@@ -37,24 +37,53 @@ def upsample4(x, mode):
     return out
 
 
+class _HostSlot:
+    """One pinned landing area for (poses, counts | status); `busy` from submit() until its handle has been read."""
+
+    def __init__(self, poses_shape, meta_shape):
+        self.poses = torch.empty(poses_shape, dtype=torch.float32).pin_memory()
+        self.meta = torch.empty(meta_shape, dtype=torch.int32).pin_memory()
+        self.busy = False
+
+
 class PendingPoses:
     """Result handle of PostProcess.submit(): the decode is queued on the stream, the finished
-    poses travel to pinned host memory asynchronously; result() waits for that copy only."""
+    poses travel to pinned host memory asynchronously; result() waits for that copy only.  Handles may be resolved in
+    any order and any number may be outstanding: each owns its pinned slot until it has been read (or dropped)."""
 
-    def __init__(self, proc, limbs, poses, meta, host_poses, host_meta, event):
+    def __init__(self, proc, limbs, poses, meta, slot, event):
         self._proc, self._limbs = proc, limbs
         self._poses, self._meta = poses, meta
-        self._host_poses, self._host_meta, self._event = host_poses, host_meta, event
+        self._slot, self._event = slot, event
+        self._out = None
 
     def result(self):
+        if self._out is not None:
+            return self._out
         self._event.synchronize()
         n = self._limbs.shape[0]
-        meta = self._host_meta.numpy()
+        meta = self._slot.meta.numpy()
         counts, status = meta[:n], meta[n:]
         if status.any():  # partial-skeleton table overflowed (rare): redo with a larger table
-            return self._proc.limb_group.group_batch(self._limbs)
-        host = self._host_poses.numpy()
-        return [host[i, :counts[i]].copy() for i in range(n)]
+            self._out = self._proc.limb_group.group_batch(self._limbs)
+        else:
+            host = self._slot.poses.numpy()
+            self._out = [host[i, :counts[i]].copy() for i in range(n)]
+        self._release()
+        return self._out
+
+    def _release(self):
+        if self._slot is not None:
+            self._slot.busy = False       # the copies above own their data: the slot may take the next batch
+            self._slot = None
+        self._limbs = self._poses = self._meta = None   # device tensors are no longer needed
+
+    def __del__(self):   # a handle dropped unread: wait for the copy that targets its slot, then free it
+        if getattr(self, '_slot', None) is not None:
+            try:
+                self._event.synchronize()
+            finally:
+                self._slot.busy = False
 
 
 class PostProcess(torch.nn.Module):
@@ -90,7 +119,7 @@ class PostProcess(torch.nn.Module):
         # the caller's next launches (the following batch's backbone) do not queue behind them
         self.group_on_side_stream = os.environ.get('OG_GROUP_SIDE_STREAM', '1') != '0'
         self._side = {}
-        self._pinned, self._flip = {}, 0
+        self._pinned = {}   # (poses shape, meta shape) -> [_HostSlot]: pinned landing areas of submit()
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
                  'device-resident grouping', feat_stage, hmp_index, omp_index, inter_mode)
 
@@ -114,18 +143,19 @@ class PostProcess(torch.nn.Module):
             limbs.record_stream(stream)
         with torch.cuda.stream(stream):
             poses, meta = self.limb_group.group_device(limbs)
-            slot = self._pinned.get(tuple(poses.shape))
+            # a pinned slot nobody is waiting on (the pool grows with the number of outstanding handles: a third submit()
+            # before the first result() gets a third slot instead of overwriting the first batch's landing area)
+            pool = self._pinned.setdefault((tuple(poses.shape), tuple(meta.shape)), [])
+            slot = next((sl for sl in pool if not sl.busy), None)
             if slot is None:
-                slot = [[torch.empty(poses.shape, dtype=torch.float32).pin_memory(),
-                         torch.empty(meta.shape, dtype=torch.int32).pin_memory()] for _ in range(2)]
-                self._pinned[tuple(poses.shape)] = slot
-            self._flip = 1 - self._flip
-            host_poses, host_meta = slot[self._flip]
-            host_poses.copy_(poses, non_blocking=True)
-            host_meta.copy_(meta, non_blocking=True)
+                slot = _HostSlot(poses.shape, meta.shape)
+                pool.append(slot)
+            slot.busy = True
+            slot.poses.copy_(poses, non_blocking=True)
+            slot.meta.copy_(meta, non_blocking=True)
             event = torch.cuda.Event()
             event.record(stream)
-        return PendingPoses(self, limbs, poses, meta, host_poses, host_meta, event)
+        return PendingPoses(self, limbs, poses, meta, slot, event)
 
     def flip_augment(self, hmps, jomps, offs, scmps, cat_flip_offs, vector_nd):
         """Merge the predictions for [images, mirrored images] (decoder/factory.py:98-146)."""

@@ -66,3 +66,18 @@ def gather_to_rank0(local_items):
     if dist.get_rank() != 0:
         return None
     return [x for part in out for x in part]
+
+
+def describe_group(device=None):
+    """What the process group really is, gathered to rank 0 (None elsewhere): {'world', 'backend', 'device_ids'} -- the
+    benchmark lines carry it so that a multi-GPU record proves how many ranks RCCL saw and which device each one used
+    (process-group bring-up as train_dist.py:151-152)."""
+    mine = None
+    if device is not None and device.type == 'cuda':
+        mine = torch.cuda.current_device()
+    if not dist.is_initialized():
+        return {'world': 1, 'backend': None, 'device_ids': [mine]}
+    ids = gather_to_rank0([mine])
+    if dist.get_rank() != 0:
+        return None
+    return {'world': dist.get_world_size(), 'backend': dist.get_backend(), 'device_ids': ids}

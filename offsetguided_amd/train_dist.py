@@ -154,8 +154,10 @@ def bench_steps(args, model, criterion, optimizer, pool, encoders, dev, rank, wo
         sharding.barrier(dev if use_cuda else None)
         comm_s = sharding.max_over_ranks(time.perf_counter() - t0, dev if use_cuda else None) / reps
         comm_ms, bus = round(comm_s * 1e3, 3), round(nbytes * 2 * (world - 1) / world / comm_s / 1e9, 1)
+    group = sharding.describe_group(dev if use_cuda else None)   # every rank takes part in the gather
     if rank == 0:
         print(json.dumps({
+            'rccl': group,
             'metric': 'training images/sec (DDP step: forward + fused losses + backward + all-reduce + fused Adam)',
             'value': round(world * args.batch_size / step_s, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.bench_steps, 'warmup': args.bench_warmup, 'ms_per_step': round(step_s * 1e3, 2),
@@ -200,8 +202,9 @@ def main(argv=None):
             model, args.checkpoint_whole, optimizer=optimizer, resume_optimizer=True, drop_layers=False, optimizer2cuda=use_cuda)
         if rank == 0:
             print(f'resumed {args.checkpoint_whole}: next epoch {start_epoch}, last train loss {start_loss:.4f}')
-    elif args.checkpoint_whole and os.path.isfile(args.checkpoint_whole):
-        # initialise from a checkpoint without its optimizer / epoch (fine-tuning, as evaluate.py:189-191 loads it)
+    elif args.checkpoint_whole:
+        # initialise from a checkpoint without its optimizer / epoch (fine-tuning, as evaluate.py:189-191 loads it); a path
+        # that does not exist is an error (load_model raises FileNotFoundError), never a silent random init
         model, *_ = models.load_model(model, args.checkpoint_whole, optimizer=None, resume_optimizer=False, drop_layers=False)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if use_cuda else None,
@@ -231,7 +234,8 @@ def main(argv=None):
     if args.bench:
         return bench_steps(args, model, criterion, optimizer, pool, encoders, dev, rank, world)
     batch_time = AverageMeter()   # over the whole run: the first steps (MIOpen find, allocator warm-up) do not bias an epoch
-    for epoch in range(start_epoch, args.epochs):
+    # --epochs MORE epochs after a resume, as the reference counts them (train_dist.py:269)
+    for epoch in range(start_epoch, start_epoch + args.epochs):
         model.train()
         losses, end, last_print = AverageMeter(), time.time(), -1
         for step in range(args.steps_per_epoch):

@@ -94,13 +94,15 @@ class EvalPreprocess:
         sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
         total = sum(h * w * 3 for h, w in sizes)
         stage = self._staging(total)
-        dev_raw = torch.empty(total, dtype=torch.uint8, device=self.device)
         o = 0
         for im, (h, w) in zip(images, sizes):          # pack the batch into ONE pinned buffer: one H2D copy
             assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'images are (h, w, 3) uint8 RGB'
             stage[0][o:o + h * w * 3].copy_(torch.from_numpy(np.ascontiguousarray(im)).reshape(-1))
             o += h * w * 3
         with torch.cuda.stream(self.copy_stream):
+            # allocated on the copy stream's pool: a block of the compute stream's pool may still be in use by kernels
+            # queued there (the host runs a batch ahead), and the copy stream does not wait for them
+            dev_raw = torch.empty(total, dtype=torch.uint8, device=self.device)
             dev_raw.copy_(stage[0][:total], non_blocking=True)
             stage[1] = torch.cuda.Event()
             stage[1].record(self.copy_stream)

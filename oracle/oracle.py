@@ -261,12 +261,17 @@ def shrink_mask_miss_u8(mask, stride):
 
 def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, person_thre=0.04,
            dist_max=40.0, use_scale=False, sort_dim=2, flip=None, materialize_offsets=False, cat_flip_offs=False,
-           scales_lr=None, jitter_lr=None, use_jitter=True):
+           scales_lr=None, jitter_lr=None, use_jitter=True, inter_mode='bicubic'):
     """PostProcess.generate_poses (decoder/factory.py:52-96) on low-res head outputs.
+
+    inter_mode = --resize-mode (decoder/factory.py:151-153): the x4 resize of the heatmaps (:74-75) and of the
+    keypoint-scale maps (:80-82); offsets and jitter maps are always bilinear (:77-78, :87-88).
 
     flip = (kp_perm, limb_perm, reserve) enables the flip-test merge first.
     Returns (poses list, dict of intermediates).
     """
+    assert inter_mode in ('bicubic', 'bilinear')
+    up = bicubic4 if inter_mode == 'bicubic' else bilinear4
     nd = 2
     if flip is not None and cat_flip_offs:
         hm_lr, off_lr = flip_cat(hm_lr, off_lr, *flip)
@@ -279,7 +284,7 @@ def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, pe
         if flip is not None:
             half = scales_lr.shape[0] // 2
             scales_lr = (scales_lr[:half] + scales_lr[half:, list(flip[0])][..., ::-1]) / np.float32(2)
-        sc_hr = bicubic4(np.ascontiguousarray(scales_lr))
+        sc_hr = up(np.ascontiguousarray(scales_lr))
     jit_hr = None
     if jitter_lr is not None:  # jitter head: flip-averaged with x negated (factory.py:108-113), then x4 bilinear
         jitter_lr = _f32(jitter_lr)
@@ -289,7 +294,7 @@ def decode(hm_lr, off_lr, skeleton, *, topk_k=32, thre_hmp=0.04, min_len=0.5, pe
             fl_j[:, 0::2] *= np.float32(-1)
             jitter_lr = (jitter_lr[:half] + fl_j) / np.float32(2)
         jit_hr = bilinear4(np.ascontiguousarray(jitter_lr))
-    hm_hr = bicubic4(hm_lr)
+    hm_hr = up(hm_lr)
     n, c, H, W = hm_hr.shape
     sc, idx, _, _ = nms_topk(hm_hr, topk_k)
     if materialize_offsets:

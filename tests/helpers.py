@@ -48,6 +48,19 @@ def jitter_case_inputs(g):
     return hm, off, jit
 
 
+def bilinear_case_inputs(g):
+    """Inputs of a --resize-mode bilinear fixture (tools/gen_golden_bilinear.py), sha-guarded; scl is None without the
+    keypoint-scale head."""
+    batch, size, flip, seed = int(g["batch"]), int(g["size"]), bool(g["flip"]), int(g["seed"])
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=8)
+    scl = None
+    if int(g["with_scale"]):
+        scl = (synth.noise_batch(seed + 5, (hm.shape[0], 17, size // 4, size // 4)) * 20 + 25).astype(np.float32)
+    shas = [sha(hm), sha(off)] + ([sha(scl)] if scl is not None else [])
+    assert shas == list(g["in_sha"]), "synthetic input generator drifted (not a parity failure)"
+    return hm, off, scl
+
+
 def load_case(name):
     """Golden case + regenerated inputs (sha-guarded against generator drift)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))

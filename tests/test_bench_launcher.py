@@ -34,6 +34,32 @@ def test_gpus_flag_spawns_that_many_ranks_dry_run():
     line = _json_line(r.stdout)
     assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1
     assert line['elapsed_s'] >= 0.02          # MAX over ranks: rank 1 sleeps 20 ms, rank 0 only 10
+    # the line proves what the process group was: two ranks, their backend, one device entry per rank
+    assert line['rccl'] == {'world': 2, 'backend': 'gloo', 'device_ids': [None, None]}
+    assert 'GPU_MAX_HW_QUEUES' in line['knobs'] and all(isinstance(v, str) for v in line['knobs'].values())
+
+
+def test_a_rank_that_dies_fails_the_whole_job_quickly():
+    """A rank-local failure must surface as a non-zero exit of `bench.py --gpus N`, not as peers waiting at the barrier."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(OG_BENCH_FAIL_RANK='1'))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]      # and no result line
+    assert time.time() - t0 < 120
+
+
+def test_wrong_results_switches_are_refused():
+    """OG_ENGINE_WHATIF (layers return uninitialised tensors) and OG_DECODER_LIB (any ablation build) must not produce a
+    benchmark line unless --allow-diagnostic, which marks it."""
+    for var in ('OG_ENGINE_WHATIF', 'OG_DECODER_LIB'):
+        r = subprocess.run([sys.executable, BENCH, '--dry-run'], capture_output=True, text=True, timeout=120,
+                           env=_clean_env(**{var: 'c160'}))
+        assert r.returncode != 0 and var in r.stderr and '--allow-diagnostic' in r.stderr
+    r = subprocess.run([sys.executable, BENCH, '--dry-run', '--allow-diagnostic'], capture_output=True, text=True, timeout=120,
+                       env=_clean_env(OG_ENGINE_WHATIF='c160'))
+    assert r.returncode == 0 and _json_line(r.stdout)['knobs']['OG_ENGINE_WHATIF'] == 'c160'
 
 
 def test_gpus_flag_must_match_the_launcher():

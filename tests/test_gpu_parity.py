@@ -375,6 +375,67 @@ def test_scale_head_golden(dev, name, fused):
         assert (limbs_hr[..., 11:] == limbs_lr[..., 11:]).all()
 
 
+@pytest.mark.parametrize("name", ["bilinear256", "bilinear256_flip", "bilinear256_scale", "bilinear256_scale_flip"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_resize_mode_bilinear_golden(dev, name, fused):
+    """generate_poses composed with --resize-mode bilinear (PostProcess.inter_mode; decoder/factory.py:151-153, :74-75,
+    :80-82), with and without the keypoint-scale head (include_scale + use_scale) and flip-test: vs the poses of the
+    reference run with that flag, and vs the oracle.  (fused_upsample only applies to bicubic: both settings must take the
+    K1a + K1 route here and agree.)"""
+    from helpers import bilinear_case_inputs
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, scl = bilinear_case_inputs(g)
+    with_scale, flip = scl is not None, bool(g["flip"])
+    p = argparse.ArgumentParser()
+    decoder.decoder_cli(p)
+    a = p.parse_args(['--resize-mode', 'bilinear', '--topk', str(FLAGS['topk']), '--thre-hmp', str(FLAGS['thre_hmp']),
+                      '--person-thre', str(FLAGS['person_thre']), '--dist-max', str(float(g["dist_max"])), '--min-len',
+                      str(FLAGS['min_len']), '--use-scale', str(with_scale)])
+    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], int(g["batch"])
+    a.include_scale, a.include_jitter_offset = with_scale, False
+    proc = decoder.decoder_factory(a)
+    assert proc.inter_mode == 'bilinear'
+    proc.fused_upsample = fused
+    t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    feats = [([None, t(hm)], [[], []], [[], []]), ([None, t(off)], [[], []], [None, t(scl)] if with_scale else [[], []])]
+    poses = proc.generate_poses(feats, flip_test=flip)
+    assert_poses_match(split_poses(g), poses, SCORE_TOL)
+    ref, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                           min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=float(g["dist_max"]),
+                           use_scale=with_scale, flip=flip_tables() if flip else None, scales_lr=scl, inter_mode='bilinear')
+    assert_poses_match(ref, poses, SCORE_TOL)
+    if with_scale:
+        for r, m in zip(split_poses(g), poses):
+            assert (r[..., 3] == m[..., 3]).all()
+
+
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 1, 0, 2), (2, 3, 1, 0)])
+def test_submit_handles_outstanding(dev, order):
+    """PostProcess.submit with several unread handles (the synchronous contract of decoder/factory.py:91-96 per batch):
+    four batches are queued before the first result() and resolved in and out of order; every handle returns ITS batch
+    (each owns a pinned slot until read), a second result() returns the same poses, and read slots are reused."""
+    proc = processor(2)
+    batches = [synth.synth_batch(900 + i, 2, 256, 256, n_persons=3 + 2 * i) for i in range(4)]
+    refs = [proc.generate_poses(features(hm, off, dev)) for hm, off in batches]
+    assert len({tuple(len(p) for p in r) for r in refs}) > 1     # the batches are distinguishable
+    handles = [proc.submit(features(hm, off, dev)) for hm, off in batches]
+    for i in order:
+        got = handles[i].result()
+        for r, m in zip(refs[i], got):
+            assert r.shape == m.shape and (r == m).all()
+        again = handles[i].result()
+        assert all((x == y).all() for x, y in zip(got, again))
+    pools = list(proc._pinned.values())
+    assert len(pools) == 1 and len(pools[0]) == 4 and not any(sl.busy for sl in pools[0])
+    more = [proc.submit(features(hm, off, dev)) for hm, off in batches[:2]]      # read slots are taken again
+    assert len(pools[0]) == 4
+    for h, r in zip(more, refs[:2]):
+        assert all((x == y).all() for x, y in zip(r, h.result()))
+    dropped = proc.submit(features(*batches[3], dev))     # a handle dropped unread frees its slot as well
+    del dropped
+    assert not any(sl.busy for sl in pools[0])
+
+
 @pytest.mark.parametrize("size,batch,k,flip", [((384, 512), 3, 48, False), ((128, 640), 2, 16, True), ((512, 256), 1, 32, False)])
 def test_generate_poses_nonsquare_vs_oracle(dev, size, batch, k, flip):
     """Non-square inputs, other batch sizes and top-k values (CLI default 48), fused and unfused, vs the oracle."""

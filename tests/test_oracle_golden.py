@@ -89,6 +89,26 @@ def test_scale_head_case(name):
         assert (r[..., 3] == m[..., 3]).all()
 
 
+BILINEAR_CASES = ["bilinear256", "bilinear256_flip", "bilinear256_scale", "bilinear256_scale_flip"]
+
+
+@pytest.mark.parametrize("name", BILINEAR_CASES)
+def test_resize_mode_bilinear_case(name):
+    """--resize-mode bilinear (decoder/factory.py:151-153; heatmaps :74-75 and scale maps :80-82 resized bilinearly), with
+    and without the keypoint-scale head and flip-test: the oracle vs poses of the reference run with that flag."""
+    from helpers import bilinear_case_inputs
+    g = np.load(f"{GOLDEN}/{name}.npz")
+    hm, off, scl = bilinear_case_inputs(g)
+    flip = flip_tables() if int(g["flip"]) else None
+    poses, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                             min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=float(g["dist_max"]),
+                             use_scale=scl is not None, flip=flip, scales_lr=scl, inter_mode='bilinear')
+    assert_poses_match(split_poses(g), poses)
+    if scl is not None:
+        for r, m in zip(split_poses(g), poses):
+            assert (r[..., 3] == m[..., 3]).all()
+
+
 def test_scored_offset_matches_reference_golden():
     """decoder/offset.py:8-43 (optional, off by default): our torch formulation is bit-identical to the reference's on
     the CPU (asserted at generation time and re-checked here through the stored hash); poses with scored_off=True."""

@@ -135,7 +135,8 @@ def test_resume_restores_epoch_weights_and_optimizer(tmp_path, monkeypatch, caps
     out0 = capsys.readouterr().out
     assert 'epoch 0 [0/2]' in out0 and 'epoch 1 [1/2]' in out0
 
-    train_dist.main(common + ['--epochs', '4', '--resume', '--checkpoint-whole', str(tmp_path / 'PoseNet_1_epoch.pth')])
+    # --epochs counts the epochs to train AFTER the resume point, as the reference does (train_dist.py:269)
+    train_dist.main(common + ['--epochs', '2', '--resume', '--checkpoint-whole', str(tmp_path / 'PoseNet_1_epoch.pth')])
     out1 = capsys.readouterr().out
     assert 'next epoch 2' in out1 and 'epoch 2 [0/2]' in out1 and 'epoch 0 [' not in out1 and 'epoch 1 [' not in out1
     assert sorted(os.listdir(tmp_path)) == first + ['PoseNet_2_epoch.pth', 'PoseNet_3_epoch.pth']
@@ -146,6 +147,8 @@ def test_resume_restores_epoch_weights_and_optimizer(tmp_path, monkeypatch, caps
 
     with pytest.raises(ValueError):
         train_dist.main(common + ['--resume'])
+    with pytest.raises(FileNotFoundError):       # a mistyped --checkpoint-whole is an error, not a silent random init
+        train_dist.main(common + ['--epochs', '1', '--checkpoint-whole', str(tmp_path / 'no_such_file.pth')])
 
 
 def test_bench_mode_prints_one_json_line_cpu(tmp_path, monkeypatch, capsys):

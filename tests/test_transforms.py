@@ -1,6 +1,8 @@
 """Input-side transforms (the part without cv2): CenterPad + ToTensor + Normalize in one HIP pass against
 the same arithmetic in torch on the CPU (torchvision's ToTensor / Normalize are `div(255)`, `sub_(mean).div_(std)`;
 torchvision.transforms.functional.pad with a colour fill is a constant border)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -161,3 +163,50 @@ def test_shrink_mask_miss_device_matches_oracle():
     assert passthrough.dtype == torch.bool and np.array_equal(passthrough.cpu().numpy()[:, 0], got)
     with pytest.raises(ValueError):
         ef._mask(m[:, :100], 3, 32, 48, torch.device('cuda:0'), 4)
+
+
+# ---- cv2-generated vectors (tools/gen_golden_cv2.py): present only once a machine with opencv-python has produced them ----
+_CV2_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'resize_cv2.npz')
+needs_cv2_golden = pytest.mark.skipif(not os.path.exists(_CV2_GOLDEN),
+                                      reason='tests/golden/resize_cv2.npz absent: no machine with cv2 has run tools/gen_golden_cv2.py '
+                                             'yet (f2 / mask-shrink parity with OpenCV itself stays unpinned)')
+
+
+def _cv2_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_golden_cv2', os.path.join(os.path.dirname(_CV2_GOLDEN), '..', '..', 'tools',
+                                                                                 'gen_golden_cv2.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(_CV2_GOLDEN)
+
+
+def _check_against_cv2(resize, shrink):
+    mod, g = _cv2_cases()
+    for i, ((h, w), T) in enumerate(mod.SMALL):
+        tw, th = mod.target(h, w, T)
+        assert np.array_equal(resize(mod.image(200 + i, h, w), th, tw), g[f'small{i}']), ('small', i)
+    for i, ((h, w), T) in enumerate(mod.CASES):
+        tw, th = mod.target(h, w, T)
+        r = resize(mod.image(100 + i, h, w), th, tw)
+        assert np.array_equal(r[:48, :48], g[f'big{i}_corner']) and mod.sha(r) == str(g[f'big{i}_sha']), ('big', i)
+    m = mod.masks()
+    for i in range(3):
+        assert np.array_equal(shrink(m, i), g['masks'][i]), ('mask', i)
+
+
+@needs_cv2_golden
+def test_oracle_resize_matches_cv2_vectors():
+    """The oracle's restatement of cv2.resize(INTER_CUBIC) and of the mask shrink against OpenCV's own outputs."""
+    import oracle
+    _check_against_cv2(lambda im, th, tw: oracle.resize_cubic_u8(im, th, tw), lambda m, i: oracle.shrink_mask_miss_u8(m[i], 4))
+
+
+@needs_cv2_golden
+@pytest.mark.gpu
+def test_device_resize_matches_cv2_vectors():
+    """og_resize_cubic_u8 / og_shrink_mask_miss_u8 against OpenCV's own outputs."""
+    from offsetguided_amd.encoder import factory as ef
+    dev = torch.device('cuda:0')
+    _check_against_cv2(lambda im, th, tw: transforms.resize_cubic(im, th, tw).cpu().numpy(),
+                       lambda m, i: ef._mask(m, 3, 32, 48, dev, 4).cpu().numpy()[i, 0])
