@@ -268,6 +268,20 @@ int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, con
                         int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2, int stride2, int relu,
                         void *workspace, size_t workspace_bytes, void *stream);
 size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int Cin2);
+/* ---- the same 3x3 stride-1 convolution for the LARGE levels (160x160 / 80x80 / 40x40 at 640x640 input), on weights tiled
+ * once in advance: csrc/conv3x3_tiled.inc -- halo-tiled direct convolution, two 4-wave workgroups per CU, 32-channel K steps,
+ * every weight stage one contiguous 8 KiB LDS image.  Same arithmetic and epilogue as og_conv3x3_bf16 (fp32 accumulation, the
+ * residual initialises the accumulators, one rounding), no workspace.
+ *   og_conv3x3_tiled_supported: 0 = shape not served (needs Cout % 128 == 0, Cin % 64 == 0, and H, W multiples of 16 or
+ *     W == 40 with H % 4 == 0), otherwise the tile kind.
+ *   og_conv3x3_pack_w16: w (Cout,3,3,Cin) 16-bit (bf16 or fp16 alike) -> packed, the same number of bytes, laid out
+ *     [Cout/128][Cin/32][9 taps][128 rows x 64 B] with the k order / slot swizzle the kernel's fragment reads expect.
+ *   og_conv3x3_tiled_bf16: x (N,H,W,Cin), skip / out (N,H,W,Cout), bias fp32[Cout]; replaces convolution.forward
+ *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
+int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout);
+int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, void *packed, void *stream);
+int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
+                          int W, int Cin, int Cout, int relu, void *stream);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 /* ---- the same entry points for fp16 activations / weights (the reference evaluates in fp16 through apex O2,
@@ -282,6 +296,8 @@ int og_stem7x7_f16(const float *images, const void *w_packed, const float *bias,
                    void *stream);
 int og_conv3x3_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
                    int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv3x3_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
+                         int W, int Cin, int Cout, int relu, void *stream);
 int og_conv2d_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin, int Win,
                   int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv2d_proj_f16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,

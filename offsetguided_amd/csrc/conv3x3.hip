@@ -31,6 +31,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lp_dtype.h"
 #include "og_common.h"
 
@@ -880,6 +882,8 @@ int halo_kind(long M, int H, int W, int Cin, int Cout)
     return M >= 8192 ? kind : 0;
 }
 
+#include "conv3x3_tiled.inc"
+
 }  // namespace
 
 // Debug aid (tools/conv_bench.py --stamps): device buffer of [workgroups][8] u64 that later launches fill with
@@ -1070,4 +1074,62 @@ OG_API int OG_LP_NAME(og_conv2d_proj)(const void *x, const void *w_cat, const fl
     pj.x2 = x2; pj.H2 = H2; pj.W2 = W2; pj.Cin2 = Cin2; pj.stride2 = stride2;
     return conv_run(OG_LP_STR("og_conv2d_proj"), x, w_cat, bias, nullptr, out, N, Hin, Win, Cin, Cout, ksize, stride, relu, workspace,
                     workspace_bytes, stream, pj);
+}
+
+// ---- the tiled kernel (conv3x3_tiled.inc): pre-tiled weights, two workgroups per CU ----
+#ifndef OG_DT_F16
+OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    if ((long)N * H * W * Cin >= (1l << 30) || (long)N * H * W * Cout >= (1l << 30)) return 0;
+    return tiled_kind(H, W, Cin, Cout);
+}
+
+OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, void *packed, void *stream)
+{
+    OG_REQUIRE(w && packed, OG_EINVAL, "og_conv3x3_pack_w16: null pointer");
+    OG_REQUIRE(Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 128 == 0, OG_EUNSUPPORTED,
+               "og_conv3x3_pack_w16: Cin must be a multiple of 64 and Cout of 128 (got %d -> %d)", Cin, Cout);
+    const long slots = (long)Cout * 9 * Cin / 8;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)w, (unsigned short *)packed, Cin, Cout);
+    OG_LAUNCH_CHECK("og_conv3x3_pack_w16");
+    return OG_OK;
+}
+#endif
+
+OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N,
+                                        int H, int W, int Cin, int Cout, int relu, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv3x3_tiled");
+    OG_REQUIRE(x && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
+    const long M = (long)N * H * W;
+    OG_REQUIRE(M * (long)Cin < (1l << 30) && M * (long)Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
+    const int kind = tiled_kind(H, W, Cin, Cout);
+    OG_REQUIRE(kind != 0, OG_EUNSUPPORTED, "%s: needs Cout %% 128 == 0, Cin %% 64 == 0 and H, W multiples of 16 or W == 40 with H %% 4 == 0 "
+               "(got %dx%d, %d -> %d)", name, H, W, Cin, Cout);
+    ConvArgs h = {};
+    h.x = (const unsigned short *)x; h.w = (const unsigned short *)w_packed; h.bias = bias;
+    h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out;
+    h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
+    h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
+    h.x_bytes = (int)(M * Cin * 2);
+    h.w_bytes = Cout * 9 * Cin * 2;
+    hipStream_t st = (hipStream_t)stream;
+#define TILED_LAUNCH(TW_, TH_, WM_)                                                                                   \
+    do {                                                                                                              \
+        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 5 + 255) / 256, lds_ = 2 * npa_ * 4096 + 3 * 128 * 64;          \
+        static OgAttrOnce attr_;                                                                                      \
+        if (attr_.need())                                                                                             \
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                              \
+        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
+        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(256), lds_, st, h);    \
+    } while (0)
+    if (kind == 1) TILED_LAUNCH(16, 16, 4);
+    else TILED_LAUNCH(40, 4, 2);
+#undef TILED_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
 }

@@ -70,6 +70,9 @@ CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
 # ... and layers with at least this many pixels run on its halo-tiled variant where a tile shape exists: H, W multiples
 # of 16 (the 160x160 / 80x80 levels) or W == 40 (the 40x40 level).
 CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
+# The large levels' 3x3 layers run on the second-generation tiled kernel (og_conv3x3_tiled_*: two workgroups per CU,
+# pre-tiled weights) where it serves the shape; OG_CONV_TILED=0 keeps them on the first-generation halo kernel.
+CONV_TILED = int(os.environ.get('OG_CONV_TILED', '1'))
 CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
@@ -110,6 +113,7 @@ class _Conv:
         self.b32 = b.float().contiguous()
         self.b = b.to(dtype)
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
+        self.w_tiled = None          # weights in og_conv3x3_tiled_*'s layout, made on first use
         self.fused = fused and w.shape[0] % 8 == 0
         strides = ((1, 1), (2, 2)) if int(os.environ.get('OG_ENGINE_CONV_S2', '1')) else ((1, 1),)
         self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) in strides
@@ -162,6 +166,16 @@ class _Conv:
         lib = _lib.load()
         out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
                           memory_format=torch.channels_last)
+        if (CONV_TILED and st == 1 and n * h * w >= CONV3X3_HALO_MIN_PIXELS
+                and lib.og_conv3x3_tiled_supported(n, h, w, c, cout)):
+            if self.w_tiled is None:     # tiled once, during the warm-up passes (never inside graph capture)
+                assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+                self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
+                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+            _lib.check(_lib.lp(lib, 'og_conv3x3_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
+                                                               _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w,
+                                                               c, cout, int(self.relu), _lib.stream_ptr(x.device)), lib)
+            return out
         ws = _conv3x3_workspace(x.device, lib.og_conv2d_workspace_bytes(n, h, w, c, cout, 3, st))
         _lib.check(_lib.lp(lib, 'og_conv2d', x.dtype)(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
                                       _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout, 3, st,

@@ -201,6 +201,72 @@ def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
         assert err <= 6e-3, f'relative error {err}'
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256),
+                                   (1, 4, 40, 64, 128), (2, 40, 40, 384, 384), (1, 12, 40, 128, 256), (3, 16, 32, 64, 384)])
+def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
+    """og_conv3x3_tiled_* (csrc/conv3x3_tiled.inc: two 4-wave workgroups per CU, pre-tiled weights, 32-channel K steps) vs an
+    fp32 torch convolution of the same 16-bit operands, with and without the residual / ReLU epilogue; bit-identical
+    results when launched again (no dependence on timing), and the packing is a pure permutation of the weights."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    assert lib.og_conv3x3_tiled_supported(n, h, w, cin, cout) > 0
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + cin)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    skip = torch.randn(n, cout, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    assert torch.equal(packed.view(torch.int16).sort().values, wt.reshape(-1).view(torch.int16).sort().values)
+    fn = _lib.lp(lib, 'og_conv3x3_tiled', dtype)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    for use_skip, relu in ((True, 1), (False, 0)):
+        ref = F.conv2d(x.float(), wt.float(), bias, 1, 1)
+        ref = F.relu(ref + skip.float()) if use_skip else ref
+        outs = []
+        for _ in range(2):
+            out = torch.full_like(skip, float('nan'))
+            _lib.check(fn(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None, _lib.ptr(out),
+                          n, h, w, cin, cout, relu, _lib.stream_ptr(dev)), lib)
+            outs.append(out)
+        err = ((outs[0].float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, f'relative error {err}'
+        assert torch.equal(outs[0], outs[1])
+
+
+def test_conv3x3_tiled_repeated_full_size(dev):
+    """The 160x160 256->256 layer of the network at bs8 (1 600 workgroups, two per CU): 20 launches on rotating inputs, every
+    output equal to the first launch of its input (no race between the DMA ring, the barriers and the fragment reads under
+    full load), and equal within rounding to the first-generation halo kernel's."""
+    lib = _lib.load()
+    cl = torch.channels_last
+    g = torch.Generator(device='cpu').manual_seed(5)
+    xs = [torch.randn(8, 256, 160, 160, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(2)]
+    wt = (torch.randn(256, 256, 3, 3, generator=g) * (1.0 / 2304) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    bias = torch.randn(256, generator=g).to(dev) * 0.1
+    packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    first = [None, None]
+    for it in range(20):
+        i = it % 2
+        out = torch.empty_like(xs[i])
+        _lib.check(lib.og_conv3x3_tiled_bf16(_lib.ptr(xs[i]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(xs[1 - i]), _lib.ptr(out),
+                                             8, 160, 160, 256, 256, 1, _lib.stream_ptr(dev)), lib)
+        if first[i] is None:
+            first[i] = out
+        else:
+            assert torch.equal(out, first[i]), f'launch {it} differs'
+    ws = torch.zeros(lib.og_conv3x3_workspace_bytes(8 * 160 * 160, 256, 256), dtype=torch.uint8, device=dev)
+    old = torch.empty_like(xs[0])
+    _lib.check(lib.og_conv3x3_bf16(_lib.ptr(xs[0]), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(xs[1]), _lib.ptr(old), 8, 160, 160, 256,
+                                   256, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+    d = (old.float() - first[0].float()).abs().max().item()
+    assert d <= 2 ** -6 * max(1.0, old.float().abs().max().item()), d     # same operands, different fp32 summation order
+
+
 def test_conv3x3_halo_kernel_several_items_per_workgroup(dev):
     """OG_CONV_HALO_ITEMS (read once per process): the halo-kernel tests again in a child process with 3 work items per
     workgroup forced -- cross-item prefetch, two-half epilogue, residual re-initialisation."""

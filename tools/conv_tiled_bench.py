@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""A/B of the two large-level 3x3 kernels in ONE process, interleaved rounds (cdna_hip_programming.md rule 24):
+og_conv3x3_bf16 (first-generation halo kernel: one 8-wave workgroup per CU) against og_conv3x3_tiled_bf16 (two 4-wave
+workgroups per CU, pre-tiled weights).  Random operands, rotating activations, `reps` back-to-back launches per HIP graph;
+prints the median and the minimum us per launch over the rounds and the TFLOP/s of the median, plus the largest difference
+between the two kernels' outputs (same operands, different fp32 summation order)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from offsetguided_amd import _lib  # noqa: E402
+
+SHAPES = [(8, 160, 160, 256, 256), (8, 80, 80, 256, 256), (8, 40, 40, 384, 384), (16, 160, 160, 256, 256),
+          (8, 40, 40, 384, 256), (8, 40, 40, 256, 256)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=8)
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--only', type=int, nargs='*', default=[])
+    ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
+    cl = torch.channels_last
+    torch.manual_seed(0)
+    for si, (n, h, w, cin, cout) in enumerate(SHAPES):
+        if a.only and si not in a.only:
+            continue
+        xs = [torch.randn(n, cin, h, w, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
+        skip = torch.randn(n, cout, h, w, device=dev).to(dt).contiguous(memory_format=cl)
+        outs = [torch.empty_like(skip) for _ in range(2)]
+        wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device=dev) * 0.1
+        packed = torch.empty(wt.numel(), dtype=dt, device=dev)
+        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+        ws = torch.zeros(max(lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout), 256), dtype=torch.uint8, device=dev)
+        old_fn, new_fn = _lib.lp(lib, 'og_conv3x3', dt), _lib.lp(lib, 'og_conv3x3_tiled', dt)
+
+        def old(i, o=0):
+            _lib.check(old_fn(_lib.ptr(xs[i % 3]), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w, cin,
+                              cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+
+        def new(i, o=1):
+            _lib.check(new_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w,
+                              cin, cout, 1, _lib.stream_ptr(dev)), lib)
+
+        old(0)
+        new(0)
+        torch.cuda.synchronize()
+        diff = (outs[0].float() - outs[1].float()).abs().max().item()
+        graphs = {}
+        for name, fn in (('halo', old), ('tiled', new)):
+            for i in range(a.reps):
+                fn(i)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(a.reps):
+                    fn(i)
+            graphs[name] = g
+        times = {k: [] for k in graphs}
+        for _ in range(a.rounds):
+            for name, g in graphs.items():
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                g.replay()
+                e.record()
+                torch.cuda.synchronize()
+                times[name].append(s.elapsed_time(e) * 1e3 / a.reps)
+        flop = 2.0 * n * h * w * cout * 9 * cin
+        line = f'[{si}] {n}x{h}x{w} {cin}->{cout} {a.dtype}:'
+        for name, t in times.items():
+            t = sorted(t)
+            med = t[len(t) // 2]
+            line += f'  {name} {med:7.1f} us (min {t[0]:7.1f}) = {flop / med / 1e6:6.0f} TFLOP/s'
+        print(line + f'  | max |halo - tiled| = {diff:.4f}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
