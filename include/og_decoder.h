@@ -275,13 +275,23 @@ size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout
  *   og_conv3x3_tiled_supported: 0 = shape not served (needs Cout % 128 == 0, Cin % 64 == 0, and H, W multiples of 16 or
  *     W == 40 with H % 4 == 0), otherwise the tile kind.
  *   og_conv3x3_pack_w16: w (Cout,3,3,Cin) 16-bit (bf16 or fp16 alike) -> packed, the same number of bytes, laid out
- *     [Cout/128][Cin/32][9 taps][128 rows x 64 B] with the k order / slot swizzle the kernel's fragment reads expect.
+ *     [Cout/128][Cin/32][9 taps][128 rows x 64 B] with the k order / slot swizzle the kernel's fragment reads expect;
+ *     order 0 = taps in their own order (for og_conv3x3_tiled_*), order 1 = the order the stride-2 kernel consumes them
+ *     (0 2 6 8 | 3 5 | 1 7 | 4, for og_conv3x3s2_tiled_*).
  *   og_conv3x3_tiled_bf16: x (N,H,W,Cin), skip / out (N,H,W,Cout), bias fp32[Cout]; replaces convolution.forward
  *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
 int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout);
-int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, void *packed, void *stream);
+int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream);
 int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
                           int W, int Cin, int Cout, int relu, void *stream);
+/* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
+ * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
+ * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.
+ * og_conv3x3s2_tiled_supported(N, Hin, Win, Cin, Cout): needs Hin, Win even, an output of 8k x 16k pixels, Cout % 128 == 0,
+ * Cin % 64 == 0. */
+int og_conv3x3s2_tiled_supported(int N, int Hin, int Win, int Cin, int Cout);
+int og_conv3x3s2_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
+                            int Win, int Cin, int Cout, int relu, void *stream);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 /* ---- the same entry points for fp16 activations / weights (the reference evaluates in fp16 through apex O2,
@@ -298,6 +308,8 @@ int og_conv3x3_f16(const void *x, const void *w, const float *bias, const void *
                    int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv3x3_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
                          int W, int Cin, int Cout, int relu, void *stream);
+int og_conv3x3s2_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
+                           int Win, int Cin, int Cout, int relu, void *stream);
 int og_conv2d_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin, int Win,
                   int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv2d_proj_f16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,

@@ -1078,6 +1078,14 @@ OG_API int OG_LP_NAME(og_conv2d_proj)(const void *x, const void *w_cat, const fl
 
 // ---- the tiled kernel (conv3x3_tiled.inc): pre-tiled weights, two workgroups per CU ----
 #ifndef OG_DT_F16
+// stride 2: H, W = INPUT size (even); served when the output is a multiple of 8 rows x 16 columns
+OG_API int og_conv3x3s2_tiled_supported(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (H & 1) || (W & 1)) return 0;
+    if ((long)N * H * W * Cin >= (1l << 30) || (long)N * H * W * Cout >= (1l << 32)) return 0;
+    return (Cout % 128 == 0 && Cin % 64 == 0 && (H / 2) % 8 == 0 && (W / 2) % 16 == 0) ? 1 : 0;
+}
+
 OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
 {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -1085,14 +1093,15 @@ OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
     return tiled_kind(H, W, Cin, Cout);
 }
 
-OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, void *packed, void *stream)
+OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream)
 {
+    OG_REQUIRE(order == 0 || order == 1, OG_EINVAL, "og_conv3x3_pack_w16: order is 0 (stride 1) or 1 (stride 2)");
     OG_REQUIRE(w && packed, OG_EINVAL, "og_conv3x3_pack_w16: null pointer");
     OG_REQUIRE(Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 128 == 0, OG_EUNSUPPORTED,
                "og_conv3x3_pack_w16: Cin must be a multiple of 64 and Cout of 128 (got %d -> %d)", Cin, Cout);
     const long slots = (long)Cout * 9 * Cin / 8;
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short *)w, (unsigned short *)packed, Cin, Cout);
+                       (const unsigned short *)w, (unsigned short *)packed, Cin, Cout, order);
     OG_LAUNCH_CHECK("og_conv3x3_pack_w16");
     return OG_OK;
 }
@@ -1117,19 +1126,73 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
     h.x_bytes = (int)(M * Cin * 2);
     h.w_bytes = Cout * 9 * Cin * 2;
     hipStream_t st = (hipStream_t)stream;
-#define TILED_LAUNCH(TW_, TH_, WM_)                                                                                   \
+#define TILED_LAUNCH(TW_, TH_, WM_, VAR_)                                                                             \
     do {                                                                                                              \
         constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 5 + 255) / 256, lds_ = 2 * npa_ * 4096 + 3 * 128 * 64;          \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
-            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_>,                              \
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>,                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                              \
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
-        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(256), lds_, st, h);    \
+        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
     } while (0)
-    if (kind == 1) TILED_LAUNCH(16, 16, 4);
-    else TILED_LAUNCH(40, 4, 2);
+    // OG_TILED_VAR (tuning phase): bits 0-3 = the kernel's VAR switches, 16 = 2 x 2 waves (128 pixels x 64 couts each)
+    const char *ve = getenv("OG_TILED_VAR");
+    const int var = ve ? atoi(ve) : 0;
+    if (kind == 1) {
+        switch (var) {
+        case 0: TILED_LAUNCH(16, 16, 4, 0); break;
+        case 2: TILED_LAUNCH(16, 16, 4, 2); break;
+        case 8: TILED_LAUNCH(16, 16, 4, 8); break;
+        default: TILED_LAUNCH(16, 16, 4, 10); break;   // weight-fragment prefetch + DMA issue behind the reads: measured best
+        }
+    } else {
+        switch (var) {
+        case 32: TILED_LAUNCH(20, 4, 1, 0); break;     // 80-pixel tiles: twice the workgroups
+        case 34: TILED_LAUNCH(20, 4, 1, 2); break;
+        case 0: TILED_LAUNCH(40, 4, 2, 0); break;
+        default: TILED_LAUNCH(40, 4, 2, 2); break;
+        }
+    }
 #undef TILED_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out,
+                                          int N, int Hin, int Win, int Cin, int Cout, int relu, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv3x3s2_tiled");
+    OG_REQUIRE(x && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && Hin > 0 && Win > 0 && !(Hin & 1) && !(Win & 1), OG_EINVAL, "%s: bad shape", name);
+    const int H = Hin / 2, W = Win / 2;
+    const long M = (long)N * H * W, Min = (long)N * Hin * Win;
+    OG_REQUIRE(Min * (long)Cin < (1l << 30) && M * (long)Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
+    OG_REQUIRE(Cout % 128 == 0 && Cin % 64 == 0 && H % 8 == 0 && W % 16 == 0, OG_EUNSUPPORTED,
+               "%s: needs Cout %% 128 == 0, Cin %% 64 == 0 and an output of 8k x 16k pixels (got %dx%d -> %dx%d, %d -> %d)", name,
+               Hin, Win, H, W, Cin, Cout);
+    ConvArgs h = {};
+    h.x = (const unsigned short *)x; h.w = (const unsigned short *)w_packed; h.bias = bias;
+    h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out;
+    h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
+    h.Hin = Hin; h.Win = Win; h.stride = 2; h.taps = 9;
+    h.x_bytes = (int)(Min * Cin * 2);
+    h.w_bytes = Cout * 9 * Cin * 2;
+    constexpr int lds_ = 3 * 128 * 64 + 3 * 3 * 4096;
+    const char *ve = getenv("OG_TILED_S2_VAR");
+    const int var = ve ? atoi(ve) : 0;
+    const long blocks = (long)N * (H / 8) * (W / 16) * h.n_tiles;
+#define S2_LAUNCH(VAR_)                                                                                               \
+    do {                                                                                                              \
+        static OgAttrOnce attr_;                                                                                      \
+        if (attr_.need())                                                                                             \
+            (void)hipFuncSetAttribute((const void *)conv3x3s2_tiled_kernel<16, 8, VAR_>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                              \
+        hipLaunchKernelGGL((conv3x3s2_tiled_kernel<16, 8, VAR_>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, h); \
+    } while (0)
+    if (ve && var == 0) S2_LAUNCH(0);
+    else S2_LAUNCH(2);       // DMA issue behind the fragment reads: measured 1-4 % faster
+#undef S2_LAUNCH
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -155,7 +155,27 @@ class _Conv:
                     pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
                     and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
                 return self._hip(x, skip)
+            if (st == 2 and CONV_TILED and x.is_contiguous(memory_format=torch.channels_last)
+                    and _lib.load().og_conv3x3s2_tiled_supported(n, h, w, c, self.w.shape[0])):
+                if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+                    skip = skip.contiguous(memory_format=torch.channels_last)
+                return self._tiled_s2(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
+
+    def _tiled_s2(self, x, skip):
+        """3x3 stride 2 on og_conv3x3s2_tiled_* (the large down-sampling layers: 320 -> 160, 160 -> 80), epilogue fused."""
+        n, c, h, w = x.shape
+        cout = self.w.shape[0]
+        lib = _lib.load()
+        if self.w_tiled is None:
+            assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+            self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
+            _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 1, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+        out = torch.empty((n, cout, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lp(lib, 'og_conv3x3s2_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
+                                                             _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c,
+                                                             cout, int(self.relu), _lib.stream_ptr(x.device)), lib)
+        return out
 
     def _hip(self, x, skip):
         n, c, h, w = x.shape
@@ -171,7 +191,7 @@ class _Conv:
             if self.w_tiled is None:     # tiled once, during the warm-up passes (never inside graph capture)
                 assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
                 self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
-                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 0, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
             _lib.check(_lib.lp(lib, 'og_conv3x3_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
                                                                _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w,
                                                                c, cout, int(self.relu), _lib.stream_ptr(x.device)), lib)

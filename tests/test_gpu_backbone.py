@@ -219,7 +219,7 @@ def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
     bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
     skip = torch.randn(n, cout, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
     packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
-    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
     assert torch.equal(packed.view(torch.int16).sort().values, wt.reshape(-1).view(torch.int16).sort().values)
     fn = _lib.lp(lib, 'og_conv3x3_tiled', dtype)
     tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
@@ -237,6 +237,46 @@ def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 128), (2, 32, 32, 128, 256), (1, 48, 64, 192, 128), (2, 160, 160, 256, 256),
+                                   (1, 16, 96, 64, 384), (1, 320, 320, 128, 256)])
+def test_conv3x3s2_tiled_kernel_matches_torch(dev, shape, dtype):
+    """og_conv3x3s2_tiled_* (stride 2, pad 1: the four input-parity phase images of a 16 x 8 output tile gathered by LDS-DMA,
+    weights pre-tiled in the order the phase groups consume them) vs an fp32 torch convolution of the same 16-bit operands;
+    borders (top / left zero padding lives in the odd phases), residual + ReLU epilogue, repeat launches bit-identical."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    assert lib.og_conv3x3s2_tiled_supported(n, h, w, cin, cout) == 1
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + cin + 7)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    skip = torch.randn(n, cout, h // 2, w // 2, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 1, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    assert torch.equal(packed.view(torch.int16).sort().values, wt.reshape(-1).view(torch.int16).sort().values)
+    fn = _lib.lp(lib, 'og_conv3x3s2_tiled', dtype)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    for use_skip, relu in ((False, 1), (True, 1), (False, 0)):
+        ref = F.conv2d(x.float(), wt.float(), bias, 2, 1)
+        ref = ref + skip.float() if use_skip else ref
+        ref = F.relu(ref) if relu else ref
+        outs = []
+        for _ in range(2):
+            out = torch.full_like(skip, float('nan'))
+            _lib.check(fn(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None, _lib.ptr(out),
+                          n, h, w, cin, cout, relu, _lib.stream_ptr(dev)), lib)
+            outs.append(out)
+        err = ((outs[0].float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, f'relative error {err}'
+        assert torch.equal(outs[0], outs[1])
+    assert lib.og_conv3x3s2_tiled_supported(1, 30, 32, 64, 128) == 0 and lib.og_conv3x3s2_tiled_supported(1, 16, 32, 64, 64) == 0
+    rc = fn(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), None, _lib.ptr(outs[0]), 1, 30, 32, 64, 128, 1, _lib.stream_ptr(dev))
+    assert rc == _lib.OG_EUNSUPPORTED
+
+
 def test_conv3x3_tiled_repeated_full_size(dev):
     """The 160x160 256->256 layer of the network at bs8 (1 600 workgroups, two per CU): 20 launches on rotating inputs, every
     output equal to the first launch of its input (no race between the DMA ring, the barriers and the fragment reads under
@@ -248,7 +288,7 @@ def test_conv3x3_tiled_repeated_full_size(dev):
     wt = (torch.randn(256, 256, 3, 3, generator=g) * (1.0 / 2304) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
     bias = torch.randn(256, generator=g).to(dev) * 0.1
     packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
-    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
     first = [None, None]
     for it in range(20):
         i = it % 2

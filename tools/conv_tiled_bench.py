@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16')
+    ap.add_argument('--vars', type=int, nargs='*', default=[0], help='OG_TILED_VAR values to compare (tuning switches of the tiled kernel)')
+    ap.add_argument('--no-halo', action='store_true', help='skip the first-generation kernel')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()
@@ -38,7 +40,7 @@ def main():
         wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
         bias = torch.randn(cout, device=dev) * 0.1
         packed = torch.empty(wt.numel(), dtype=dt, device=dev)
-        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
         ws = torch.zeros(max(lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout), 256), dtype=torch.uint8, device=dev)
         old_fn, new_fn = _lib.lp(lib, 'og_conv3x3', dt), _lib.lp(lib, 'og_conv3x3_tiled', dt)
 
@@ -55,7 +57,10 @@ def main():
         torch.cuda.synchronize()
         diff = (outs[0].float() - outs[1].float()).abs().max().item()
         graphs = {}
-        for name, fn in (('halo', old), ('tiled', new)):
+        arms = ([] if a.no_halo else [('halo', old, None)]) + [('tiled' + (f'/v{v}' if v else ''), new, v) for v in a.vars]
+        for name, fn, var in arms:
+            if var is not None:
+                os.environ['OG_TILED_VAR'] = str(var)      # read by the library at every call: fixed at graph capture
             for i in range(a.reps):
                 fn(i)
             torch.cuda.synchronize()
@@ -82,5 +87,75 @@ def main():
         print(line + f'  | max |halo - tiled| = {diff:.4f}', flush=True)
 
 
+def main_s2():
+    """--s2: og_conv3x3s2_tiled_bf16 against MIOpen's stride-2 convolution + og_bias_act_bf16 on the network's large
+    down-sampling layers, interleaved rounds."""
+    import torch.nn.functional as F
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--s2', action='store_true')
+    ap.add_argument('--reps', type=int, default=8)
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--vars', type=int, nargs='*', default=[0])
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    torch.backends.cudnn.benchmark = True
+    cl = torch.channels_last
+    dt = torch.bfloat16
+    for si, (n, h, w, cin, cout) in enumerate([(8, 320, 320, 128, 256), (8, 160, 160, 256, 256), (8, 64, 64, 256, 384)]):
+        xs = [torch.randn(n, cin, h, w, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
+        wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device=dev) * 0.1
+        packed = torch.empty(wt.numel(), dtype=dt, device=dev)
+        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 1, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+        out = torch.empty((n, cout, h // 2, w // 2), dtype=dt, device=dev, memory_format=cl)
+        holder = {}
+
+        def miopen(i):
+            y = F.conv2d(xs[i % 3], wt, None, 2, 1)
+            _lib.check(lib.og_bias_act_bf16(_lib.ptr(y), _lib.ptr(bias), None, n * (h // 2) * (w // 2), cout, 1, _lib.stream_ptr(dev)), lib)
+            holder['y'] = y
+
+        def ours(i):
+            _lib.check(lib.og_conv3x3s2_tiled_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), None, _lib.ptr(out), n, h, w,
+                                                   cin, cout, 1, _lib.stream_ptr(dev)), lib)
+
+        miopen(0)
+        ours(0)
+        torch.cuda.synchronize()
+        diff = (holder['y'].float() - out.float()).abs().max().item()
+        graphs = {}
+        for name, fn, var in [('miopen+epilogue', miopen, None)] + [('tiled_s2' + (f'/v{v}' if v else ''), ours, v) for v in a.vars]:
+            if var is not None:
+                os.environ['OG_TILED_S2_VAR'] = str(var)
+            for i in range(a.reps):
+                fn(i)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(a.reps):
+                    fn(i)
+            graphs[name] = g
+        times = {k: [] for k in graphs}
+        for _ in range(a.rounds):
+            for name, g in graphs.items():
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                g.replay()
+                e.record()
+                torch.cuda.synchronize()
+                times[name].append(s.elapsed_time(e) * 1e3 / a.reps)
+        flop = 2.0 * n * (h // 2) * (w // 2) * cout * 9 * cin
+        line = f'[s2 {si}] {n}x{h}x{w} {cin}->{cout}:'
+        for name, t in times.items():
+            t = sorted(t)
+            med = t[len(t) // 2]
+            line += f'  {name} {med:7.1f} us (min {t[0]:7.1f}) = {flop / med / 1e6:6.0f} TFLOP/s'
+        print(line + f'  | max |miopen - tiled| = {diff:.4f}', flush=True)
+
+
 if __name__ == '__main__':
-    main()
+    if '--s2' in sys.argv:
+        main_s2()
+    else:
+        main()
