@@ -325,7 +325,7 @@ def main():
                       backbone_tflops=round(nb * FLOP_PER_IMAGE * (a.size * a.size) / (640 * 640) / (bb_ms * 1e-3) / 1e12, 1))
 
         # C1, the dominant backbone kernel (13 of the 3x3 convolutions, 54 % of the network's FLOPs): the 160x160 256->256
-        # layer through og_conv3x3_bf16, bias + residual + ReLU epilogue included, HIP events around back-to-back launches
+        # layer through og_conv3x3_tiled_bf16, bias + residual + ReLU epilogue included, HIP events around back-to-back launches
         # on rotating activations (the network hands it activations the previous layer just wrote)
         if a.size == 640:
             lib = _lib.load()
@@ -333,17 +333,18 @@ def main():
             xs = [torch.randn(nb, 256, 160, 160, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(3)]
             wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(torch.bfloat16).contiguous(memory_format=cl)
             cb = torch.zeros(256, device=dev)
-            cws = torch.zeros(max(lib.og_conv3x3_workspace_bytes(nb * 160 * 160, 256, 256), 256), dtype=torch.uint8, device=dev)
+            packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
 
             def conv_once(i):
-                _lib.check(lib.og_conv3x3_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(wt), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
-                                               _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, _lib.ptr(cws), cws.numel(),
-                                               _lib.stream_ptr(dev)), lib)
+                _lib.check(lib.og_conv3x3_tiled_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
+                                                     _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, _lib.stream_ptr(dev)), lib)
             timed(conv_once, 5)
             conv_us = timed(conv_once, 30) * 1e3
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
-                'kernel': 'C1 = og_conv3x3_bf16 (conv3x3_halo_kernel<16,16,4>) on the 160x160 256->256 layer, epilogue fused',
+                'kernel': 'C1 = og_conv3x3_tiled_bf16 (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
+                          '256->256 layer, residual + bias + ReLU epilogue fused',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
                 'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
                 'frac': round(conv_flop / (conv_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

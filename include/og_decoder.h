@@ -277,7 +277,8 @@ size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout
  *   og_conv3x3_pack_w16: w (Cout,3,3,Cin) 16-bit (bf16 or fp16 alike) -> packed, the same number of bytes, laid out
  *     [Cout/128][Cin/32][9 taps][128 rows x 64 B] with the k order / slot swizzle the kernel's fragment reads expect;
  *     order 0 = taps in their own order (for og_conv3x3_tiled_*), order 1 = the order the stride-2 kernel consumes them
- *     (0 2 6 8 | 3 5 | 1 7 | 4, for og_conv3x3s2_tiled_*).
+ *     (0 2 6 8 | 3 5 | 1 7 | 4, for og_conv3x3s2_tiled_*); order 2 / 3 = a 1x1 weight (Cout, Cin) in cout tiles of 128 / 64 rows
+ *     with k in its natural order (for og_conv1x1_tiled_* / og_conv1x1_heads_*).
  *   og_conv3x3_tiled_bf16: x (N,H,W,Cin), skip / out (N,H,W,Cout), bias fp32[Cout]; replaces convolution.forward
  *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
 int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout);
@@ -292,6 +293,21 @@ int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias
 int og_conv3x3s2_tiled_supported(int N, int Hin, int Win, int Cin, int Cout);
 int og_conv3x3s2_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
                             int Win, int Cin, int Cout, int relu, void *stream);
+/* ---- pointwise (1x1) convolutions of the large levels (csrc/conv3x3_tiled.inc, conv1x1_tiled_kernel) ----
+ * og_conv1x1_tiled_bf16: out (N,H,W,Cout) = act(W [x1 | x2] + bias (+ skip)): output pixel (y, x) reads x1 (N,H1,W1,C1) at
+ *   (y * stride1, x * stride1); an optional second input x2 of the SAME shape and stride is concatenated along K -- the
+ *   inters_ / cnvs_ junction relu(bn(conv(inter)) + bn(conv(feat))) of models/hourglass_104.py:239-250, :291-292 in one launch --
+ *   and stride 2 with one input is the 1x1 projection `skip` of the down-sampling residuals (:63-67).  w_packed: the
+ *   (Cout, C1 + C2) weight through og_conv3x3_pack_w16(order 2); C1, C2 multiples of 64, Cout of 128; bias / skip may be null.
+ * og_conv1x1_heads_bf16: all heads of the decoded stack as one 1x1 convolution (models/heads.py:48-70, :116-142, no
+ *   activation): x (N,H,W,C) -> up to four dense fp32 NCHW tensors outs[i] (N,head_channels[i],H,W), written straight from the
+ *   fp32 accumulators (bias added in fp32, no 16-bit rounding).  w_packed: the concatenated head weights padded to Cout (a
+ *   multiple of 64) through og_conv3x3_pack_w16(order 3); bias fp32[Cout]. */
+int og_conv1x1_tiled_bf16(const void *x1, int C1, int H1, int W1, int stride1, const void *x2, int C2, int H2, int W2, int stride2,
+                          const void *w_packed, const float *bias, const void *skip, void *out, int N, int H, int W, int Cout,
+                          int relu, void *stream);
+int og_conv1x1_heads_bf16(const void *x, int C, const void *w_packed, const float *bias, int N, int H, int W, int Cout, int n_heads,
+                          const int *head_channels, float *const *outs, void *stream);
 /* Debug aid: later og_conv3x3_bf16 launches write [workgroup][8] u64 s_memrealtime (100 MHz) marks into `buf`
  * (device memory, 64 B per workgroup); NULL switches it off. */
 /* ---- the same entry points for fp16 activations / weights (the reference evaluates in fp16 through apex O2,
@@ -310,6 +326,11 @@ int og_conv3x3_tiled_f16(const void *x, const void *w_packed, const float *bias,
                          int W, int Cin, int Cout, int relu, void *stream);
 int og_conv3x3s2_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
                            int Win, int Cin, int Cout, int relu, void *stream);
+int og_conv1x1_tiled_f16(const void *x1, int C1, int H1, int W1, int stride1, const void *x2, int C2, int H2, int W2, int stride2,
+                         const void *w_packed, const float *bias, const void *skip, void *out, int N, int H, int W, int Cout,
+                         int relu, void *stream);
+int og_conv1x1_heads_f16(const void *x, int C, const void *w_packed, const float *bias, int N, int H, int W, int Cout, int n_heads,
+                         const int *head_channels, float *const *outs, void *stream);
 int og_conv2d_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int Hin, int Win,
                   int Cin, int Cout, int ksize, int stride, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv2d_proj_f16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,

@@ -1095,11 +1095,12 @@ OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
 
 OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream)
 {
-    OG_REQUIRE(order == 0 || order == 1, OG_EINVAL, "og_conv3x3_pack_w16: order is 0 (stride 1) or 1 (stride 2)");
+    OG_REQUIRE(order >= 0 && order <= 3, OG_EINVAL,
+               "og_conv3x3_pack_w16: order is 0 / 1 (3x3, stride 1 / 2) or 2 / 3 (1x1, cout tiles of 128 / 64)");
     OG_REQUIRE(w && packed, OG_EINVAL, "og_conv3x3_pack_w16: null pointer");
-    OG_REQUIRE(Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 128 == 0, OG_EUNSUPPORTED,
-               "og_conv3x3_pack_w16: Cin must be a multiple of 64 and Cout of 128 (got %d -> %d)", Cin, Cout);
-    const long slots = (long)Cout * 9 * Cin / 8;
+    OG_REQUIRE(Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % (order == 3 ? 64 : 128) == 0, OG_EUNSUPPORTED,
+               "og_conv3x3_pack_w16: Cin must be a multiple of 64 and Cout of %d (got %d -> %d)", order == 3 ? 64 : 128, Cin, Cout);
+    const long slots = (long)Cout * (order >= 2 ? 1 : 9) * Cin / 8;
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short *)w, (unsigned short *)packed, Cin, Cout, order);
     OG_LAUNCH_CHECK("og_conv3x3_pack_w16");
@@ -1128,14 +1129,17 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
     hipStream_t st = (hipStream_t)stream;
 #define TILED_LAUNCH(TW_, TH_, WM_, VAR_)                                                                             \
     do {                                                                                                              \
-        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 5 + 255) / 256, lds_ = 2 * npa_ * 4096 + 3 * 128 * 64;          \
+        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 5 + 255) / 256;                                                 \
+        const int lds_ = 2 * npa_ * 4096 + 3 * 128 * 64 + lds_extra;                                                  \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
             (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>,                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
         hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
     } while (0)
+    // OG_TILED_LDS_EXTRA (experiment): bytes of LDS requested on top of the kernel's own: 16384 leaves one workgroup per CU
+    static const int lds_extra = getenv("OG_TILED_LDS_EXTRA") ? atoi(getenv("OG_TILED_LDS_EXTRA")) : 0;
     // OG_TILED_VAR (tuning phase): bits 0-3 = the kernel's VAR switches, 16 = 2 x 2 waves (128 pixels x 64 couts each)
     const char *ve = getenv("OG_TILED_VAR");
     const int var = ve ? atoi(ve) : 0;
@@ -1144,6 +1148,14 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         case 0: TILED_LAUNCH(16, 16, 4, 0); break;
         case 2: TILED_LAUNCH(16, 16, 4, 2); break;
         case 8: TILED_LAUNCH(16, 16, 4, 8); break;
+#ifdef OG_TILED_ABLATIONS     // timing-only builds (wrong results): tools/build_variants.sh conv3x3.hip abl "-DOG_TILED_ABLATIONS"
+        case 26: TILED_LAUNCH(16, 16, 4, 26); break;     // 10 + no DMA
+        case 42: TILED_LAUNCH(16, 16, 4, 42); break;     // 10 + fragments read once
+        case 74: TILED_LAUNCH(16, 16, 4, 74); break;     // 10 + no barrier
+        case 58: TILED_LAUNCH(16, 16, 4, 58); break;     // 10 + no DMA + fragments read once
+        case 122: TILED_LAUNCH(16, 16, 4, 122); break;   // MFMA only
+        case 138: TILED_LAUNCH(16, 16, 4, 138); break;   // 10 + waits relaxed by one step
+#endif
         default: TILED_LAUNCH(16, 16, 4, 10); break;   // weight-fragment prefetch + DMA issue behind the reads: measured best
         }
     } else {
@@ -1193,6 +1205,76 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
     if (ve && var == 0) S2_LAUNCH(0);
     else S2_LAUNCH(2);       // DMA issue behind the fragment reads: measured 1-4 % faster
 #undef S2_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+// ---- pointwise (1x1) convolutions of the large levels (conv1x1_tiled_kernel) ----
+static int pw_fill(const char *name, PwArgs &a, const void *x1, int C1, int H1, int W1, int s1, const void *x2, int C2, int H2, int W2,
+                   int s2, const void *w_packed, const float *bias, int N, int H, int W, int Cout, int bn)
+{
+    OG_REQUIRE(x1 && w_packed, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && H > 0 && W > 0 && (s1 == 1 || s1 == 2) && (!x2 || s2 == 1 || s2 == 2), OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(C1 > 0 && C1 % 64 == 0 && (!x2 || (C2 > 0 && C2 % 64 == 0)) && Cout % bn == 0, OG_EUNSUPPORTED,
+               "%s: input channels must be multiples of 64 and Cout of %d (got %d + %d -> %d)", name, bn, C1, x2 ? C2 : 0, Cout);
+    OG_REQUIRE((H - 1) * s1 < H1 && (W - 1) * s1 < W1, OG_EINVAL, "%s: the strided output reaches outside the input", name);
+    OG_REQUIRE(!x2 || (C2 == C1 && H2 == H1 && W2 == W1 && s2 == s1), OG_EUNSUPPORTED,
+               "%s: a second input must have the shape and stride of the first", name);
+    const long M = (long)N * H * W;
+    OG_REQUIRE((long)N * H1 * W1 * C1 < (1l << 30) && (!x2 || (long)N * H2 * W2 * C2 < (1l << 30)) && M * Cout < (1l << 30), OG_EUNSUPPORTED,
+               "%s: tensor too large (>= 2 GiB)", name);
+    a.x1 = (const unsigned short *)x1; a.x2 = (const unsigned short *)x2; a.w = (const unsigned short *)w_packed; a.bias = bias;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.M = (int)M;
+    a.C1 = C1; a.H1 = H1; a.W1 = W1; a.s1 = s1;
+    a.C2 = x2 ? C2 : 0; a.H2 = H2; a.W2 = W2; a.s2 = s2;
+    a.x1_bytes = (int)((long)N * H1 * W1 * C1 * 2);
+    a.x2_bytes = x2 ? (int)((long)N * H2 * W2 * C2 * 2) : 0;
+    a.w_bytes = Cout * (a.C1 + a.C2) * 2;
+    a.n_tiles = Cout / bn;
+    return OG_OK;
+}
+
+OG_API int OG_LP_NAME(og_conv1x1_tiled)(const void *x1, int C1, int H1, int W1, int stride1, const void *x2, int C2, int H2, int W2,
+                                        int stride2, const void *w_packed, const float *bias, const void *skip, void *out, int N,
+                                        int H, int W, int Cout, int relu, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv1x1_tiled");
+    OG_REQUIRE(out, OG_EINVAL, "%s: null pointer", name);
+    PwArgs a = {};
+    const int rc = pw_fill(name, a, x1, C1, H1, W1, stride1, x2, C2, H2, W2, stride2, w_packed, bias, N, H, W, Cout, 128);
+    if (rc != OG_OK) return rc;
+    a.skip = (const unsigned short *)skip; a.out = (unsigned short *)out; a.relu = relu;
+    constexpr int lds_ = 3 * 2 * 128 * 64;
+    const long blocks = (long)((a.M + 255) / 256) * a.n_tiles;
+    hipLaunchKernelGGL((conv1x1_tiled_kernel<128, 0>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int OG_LP_NAME(og_conv1x1_heads)(const void *x, int C, const void *w_packed, const float *bias, int N, int H, int W, int Cout,
+                                        int n_heads, const int *head_channels, float *const *outs, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv1x1_heads");
+    OG_REQUIRE(head_channels && outs && bias, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(n_heads >= 1 && n_heads <= 4, OG_EUNSUPPORTED, "%s: 1 to 4 heads", name);
+    PwArgs a = {};
+    const int rc = pw_fill(name, a, x, C, H, W, 1, nullptr, 0, 0, 0, 1, w_packed, bias, N, H, W, Cout, 64);
+    if (rc != OG_OK) return rc;
+    int c = 0;
+    for (int i = 0; i < 4; ++i) {
+        a.first[i] = c;
+        if (i < n_heads) {
+            OG_REQUIRE(head_channels[i] > 0 && outs[i], OG_EINVAL, "%s: bad head %d", name, i);
+            c += head_channels[i];
+            a.outf[i] = outs[i];
+        }
+    }
+    a.first[4] = c;
+    for (int i = n_heads; i < 4; ++i) a.first[i] = c;     // empty ranges
+    OG_REQUIRE(c <= Cout, OG_EINVAL, "%s: the heads have %d channels, the packed weight %d", name, c, Cout);
+    constexpr int lds_ = 3 * 2 * 64 * 64;
+    const long blocks = (long)((a.M + 255) / 256) * a.n_tiles;
+    hipLaunchKernelGGL((conv1x1_tiled_kernel<64, 1>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

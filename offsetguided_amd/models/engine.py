@@ -72,13 +72,20 @@ CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
 CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
 # The large levels' 3x3 layers run on the second-generation tiled kernel (og_conv3x3_tiled_*: two workgroups per CU,
 # pre-tiled weights) where it serves the shape; OG_CONV_TILED=0 keeps them on the first-generation halo kernel.
-CONV_TILED = int(os.environ.get('OG_CONV_TILED', '1'))
+CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))   # bit 0: 3x3 stride 1, bit 1: 3x3 stride 2 (og_conv3x3s2_tiled_*), bit 2: 1x1
+# bit 2 (4): pointwise layers of the large levels (junction, projection skips, heads) on og_conv1x1_tiled_* / og_conv1x1_heads_*
+CONV_PW_MIN_PIXELS = int(os.environ.get('OG_CONV_PW_MIN_PIXELS', '8192'))
 CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
 BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fork up1 only at levels <= this depth
+# OG_ENGINE_BRANCH_DELAY = D: the up1 branches of the levels above depth D are not started at their fork point but when the
+# trunk ENTERS depth D (they only need the level's input): the trunk then descends through the large levels with the chip
+# to itself, and the bulk of the up1 branches runs beside the latency-bound 20x20 / 10x10 / 5x5 chain instead of before it.
+BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
+_pending_branches = []
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
 class _Issuer(threading.local):
@@ -155,12 +162,43 @@ class _Conv:
                     pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
                     and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
                 return self._hip(x, skip)
-            if (st == 2 and CONV_TILED and x.is_contiguous(memory_format=torch.channels_last)
+            if (st == 2 and (CONV_TILED & 2) and x.is_contiguous(memory_format=torch.channels_last)
                     and _lib.load().og_conv3x3s2_tiled_supported(n, h, w, c, self.w.shape[0])):
                 if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
                     skip = skip.contiguous(memory_format=torch.channels_last)
                 return self._tiled_s2(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
+
+    def pointwise_ok(self, x):
+        """This 1x1 layer can run on og_conv1x1_tiled_* for input x (large levels, channel multiples the kernel serves)."""
+        n, c, h, w = x.shape
+        st = self.stride[0]
+        return ((CONV_TILED & 4) and self.fused and tuple(self.w.shape[2:]) == (1, 1) and tuple(self.pad) == (0, 0)
+                and c % 64 == 0 and self.w.shape[0] % 128 == 0 and x.is_cuda
+                and n * ((h - 1) // st + 1) * ((w - 1) // st + 1) >= CONV_PW_MIN_PIXELS)
+
+    def pointwise(self, x, x2=None, other=None, bias=True, skip=None):
+        """act(W x (+ W_other x2) + bias (+ skip)) in one launch; `other` = the second 1x1 layer of the junction (its weight is
+        concatenated along K on first use, its bias is already summed into this layer's).  bias=False / relu off = raw conv."""
+        n, c, h, w = x.shape
+        st, cout = self.stride[0], self.w.shape[0]
+        ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+        lib = _lib.load()
+        if self.w_tiled is None:
+            assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+            wcat = self.w.reshape(cout, -1) if other is None else torch.cat([self.w.reshape(cout, -1), other.w.reshape(cout, -1)], 1)
+            wcat = wcat.contiguous()
+            self.w_tiled = torch.empty(wcat.numel(), dtype=self.w.dtype, device=self.w.device)
+            _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wcat), wcat.shape[1], cout, 2, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+        assert x.is_contiguous(memory_format=torch.channels_last) and (x2 is None or (x2.shape == x.shape and x2.is_contiguous(memory_format=torch.channels_last)))
+        if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+        out = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lp(lib, 'og_conv1x1_tiled', x.dtype)(
+            _lib.ptr(x), c, h, w, st, _lib.ptr(x2) if x2 is not None else None, c if x2 is not None else 0, h, w, st,
+            _lib.ptr(self.w_tiled), _lib.ptr(self.b32) if bias else None, _lib.ptr(skip) if skip is not None else None, _lib.ptr(out),
+            n, ho, wo, cout, int(self.relu and bias), _lib.stream_ptr(x.device)), lib)
+        return out
 
     def _tiled_s2(self, x, skip):
         """3x3 stride 2 on og_conv3x3s2_tiled_* (the large down-sampling layers: 320 -> 160, 160 -> 80), epilogue fused."""
@@ -186,7 +224,7 @@ class _Conv:
         lib = _lib.load()
         out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
                           memory_format=torch.channels_last)
-        if (CONV_TILED and st == 1 and n * h * w >= CONV3X3_HALO_MIN_PIXELS
+        if ((CONV_TILED & 1) and st == 1 and n * h * w >= CONV3X3_HALO_MIN_PIXELS
                 and lib.og_conv3x3_tiled_supported(n, h, w, c, cout)):
             if self.w_tiled is None:     # tiled once, during the warm-up passes (never inside graph capture)
                 assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
@@ -225,7 +263,12 @@ class _Residual:
         n, c, h, w = y.shape
         if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS and not _WHATIF:
             return self._proj(y, x)
-        shortcut = x if self.skip is None else self.skip.raw(x)
+        if self.skip is None:
+            shortcut = x
+        elif self.skip.pointwise_ok(x) and not _WHATIF:
+            shortcut = self.skip.pointwise(x, bias=False)      # raw projection: its bias rides on conv2's epilogue
+        else:
+            shortcut = self.skip.raw(x)
         return self.c2(y, skip=shortcut)
 
     def _proj(self, y, x):
@@ -271,13 +314,26 @@ class _Level:
                 # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work
                 prio = int(os.environ.get('OG_ENGINE_SIDE_PRIORITY', '0'))
                 self._side = torch.cuda.Stream(x.device, priority=prio)
-            self._side.wait_stream(cur)                      # fork: up1 only needs x
-            outer = _issuer.branch
-            with torch.cuda.stream(self._side):
-                _issuer.branch = self.depth + 1
-                up = _run(self.up1, x)
-                _issuer.branch = outer
+            box = {}
+
+            def start(side=self._side, depth=self.depth, box=box):
+                side.wait_stream(torch.cuda.current_stream(x.device))   # fork: up1 only needs x
+                outer = _issuer.branch
+                with torch.cuda.stream(side):
+                    _issuer.branch = depth + 1
+                    box['up'] = _run(self.up1, x)
+                    _issuer.branch = outer
+
+            if self.depth < BRANCH_DELAY:
+                _pending_branches.append(start)               # started when the trunk enters depth BRANCH_DELAY
+            else:
+                while _pending_branches:
+                    _pending_branches.pop(0)()
+                start()
             low = self._lower(x)
+            while 'up' not in box:                            # (a delay deeper than the pyramid: start before the join)
+                _pending_branches.pop(0)()
+            up = box['up']
             cur.wait_stream(self._side)                      # join before the merge
         else:
             low = self._lower(x)
@@ -343,7 +399,7 @@ class InferenceEngine:
             self.stem_w = packed.to(dtype).contiguous()
         # GPU bf16 path: all heads as ONE 1x1 convolution (output channels padded to a multiple of 8); the maps leave
         # through og_nhwc_bf16_to_nchw_f32 (bias added in fp32, one pass) instead of bias / cast / layout passes each
-        self.heads_w = None
+        self.heads_w, self.heads_tiled = None, None
         if fused:
             parts = [h for h in (self.hm, self.off, self.scale, self.jitter) if h is not None]
             self.head_channels = [h.w.shape[0] for h in parts]
@@ -386,7 +442,32 @@ class InferenceEngine:
         for s in range(self.stage + 1):
             feat = self.cnvs[s](self.kps[s](inter))
             if s < self.stage:
-                inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
+                if self.inters_[s].pointwise_ok(inter) and feat.shape == inter.shape and not _WHATIF:
+                    # relu(inters_(inter) + cnvs_(feat)) as ONE 1x1 convolution over the concatenated channels
+                    inter = self.inters[s](self.inters_[s].pointwise(inter, x2=feat, other=self.cnvs_[s]))
+                else:
+                    inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
+        if self.heads_w is not None and (CONV_TILED & 4) and feat.shape[1] % 64 == 0 and len(self.head_channels) <= 4:
+            lib = _lib.load()
+            n, c, h, w = feat.shape
+            if self.heads_tiled is None:
+                assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+                cout = (sum(self.head_channels) + 63) // 64 * 64
+                wpad = torch.zeros((cout, c), dtype=self.heads_w.dtype, device=self.heads_w.device)
+                wpad[:self.heads_w.shape[0]] = self.heads_w.reshape(self.heads_w.shape[0], -1)
+                bpad = torch.zeros(cout, dtype=torch.float32, device=self.heads_w.device)
+                bpad[:self.heads_b.shape[0]] = self.heads_b
+                packed = torch.empty(wpad.numel(), dtype=wpad.dtype, device=wpad.device)
+                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wpad), c, cout, 3, _lib.ptr(packed), _lib.stream_ptr(feat.device)), lib)
+                self.heads_tiled = (packed, bpad, cout)
+            packed, bpad, cout = self.heads_tiled
+            outs = [torch.empty((n, ch, h, w), dtype=torch.float32, device=feat.device) for ch in self.head_channels]
+            import ctypes as C
+            chans = (C.c_int * len(outs))(*self.head_channels)
+            ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            _lib.check(_lib.lp(lib, 'og_conv1x1_heads', feat.dtype)(_lib.ptr(feat), c, _lib.ptr(packed), _lib.ptr(bpad), n, h, w, cout,
+                                                                len(outs), chans, ptrs, _lib.stream_ptr(feat.device)), lib)
+            return tuple(outs)
         if self.heads_w is not None:
             lib = _lib.load()
             y = F.conv2d(feat, self.heads_w)

@@ -277,6 +277,81 @@ def test_conv3x3s2_tiled_kernel_matches_torch(dev, shape, dtype):
     assert rc == _lib.OG_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 40, 40, 256, 256, 1, True), (1, 33, 21, 128, 128, 1, False), (2, 32, 48, 128, 256, 2, False),
+                                  (1, 160, 160, 256, 256, 1, True), (3, 20, 24, 384, 256, 1, False), (1, 64, 64, 64, 384, 2, False)])
+def test_conv1x1_tiled_matches_torch(dev, case, dtype):
+    """og_conv1x1_tiled_* vs fp32 torch: one input (stride 1 / 2: the projection `skip` of the residuals, raw and with bias +
+    residual + ReLU) and two inputs concatenated along K (the inters_ / cnvs_ junction); tile tails (M not a multiple of 256)."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout, st, two = case
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 100 + cin + st)
+    cl = torch.channels_last
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(dev).to(dtype)   # noqa: E731
+    x1 = mk(n, cin, h, w).contiguous(memory_format=cl)
+    x2 = mk(n, cin, h, w).contiguous(memory_format=cl) if two else None
+    w1 = (mk(cout, cin, 1, 1).float() * (1.0 / cin) ** 0.5).to(dtype)
+    w2 = (mk(cout, cin, 1, 1).float() * (1.0 / cin) ** 0.5).to(dtype) if two else None
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+    skip = mk(n, cout, ho, wo).contiguous(memory_format=cl)
+    wcat = (torch.cat([w1.reshape(cout, -1), w2.reshape(cout, -1)], 1) if two else w1.reshape(cout, -1)).contiguous()
+    packed = torch.empty(wcat.numel(), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wcat), wcat.shape[1], cout, 2, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    fn = _lib.lp(lib, 'og_conv1x1_tiled', dtype)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    base = F.conv2d(x1.float(), w1.float(), None, st) + (F.conv2d(x2.float(), w2.float(), None, st) if two else 0)
+    for use_bias, use_skip, relu in ((False, False, 0), (True, True, 1), (True, False, 1)):
+        ref = base + (bias.view(1, -1, 1, 1) if use_bias else 0) + (skip.float() if use_skip else 0)
+        ref = F.relu(ref) if relu else ref
+        outs = []
+        for _ in range(2):
+            out = torch.full_like(skip, float('nan'))
+            _lib.check(fn(_lib.ptr(x1), cin, h, w, st, _lib.ptr(x2) if two else None, cin if two else 0, h, w, st, _lib.ptr(packed),
+                          _lib.ptr(bias) if use_bias else None, _lib.ptr(skip) if use_skip else None, _lib.ptr(out), n, ho, wo, cout,
+                          relu, _lib.stream_ptr(dev)), lib)
+            outs.append(out)
+        err = ((outs[0].float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, f'relative error {err}'
+        assert torch.equal(outs[0], outs[1])
+    rc = fn(_lib.ptr(x1), 96, h, w, st, None, 0, h, w, st, _lib.ptr(packed), None, None, _lib.ptr(outs[0]), n, ho, wo, cout, 0,
+            _lib.stream_ptr(dev))
+    assert rc == _lib.OG_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 40, 40, 256, (17, 38)), (1, 33, 21, 128, (17, 38, 17)), (1, 160, 160, 256, (17, 38)), (2, 16, 16, 64, (17, 38, 17, 2))])
+def test_conv1x1_heads_matches_torch(dev, case, dtype):
+    """og_conv1x1_heads_*: all heads as one 1x1 convolution, dense fp32 NCHW outputs per head with the bias added in fp32 (no
+    16-bit rounding of the result: the error left is the fp32 summation order)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    n, h, w, cin, heads = case
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h + cin)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    tot = sum(heads)
+    cout = (tot + 63) // 64 * 64
+    wt = torch.zeros(cout, cin, dtype=dtype, device=dev)
+    wt[:tot] = (torch.randn(tot, cin, generator=g) * (1.0 / cin) ** 0.5).to(dev).to(dtype)
+    bias = torch.zeros(cout, device=dev)
+    bias[:tot] = torch.randn(tot, generator=g).to(dev)
+    packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 3, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    outs = [torch.full((n, c, h, w), float('nan'), device=dev) for c in heads]
+    chans = (C.c_int * len(heads))(*heads)
+    ptrs = (C.c_void_p * len(heads))(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lp(lib, 'og_conv1x1_heads', dtype)(_lib.ptr(x), cin, _lib.ptr(packed), _lib.ptr(bias), n, h, w, cout, len(heads),
+                                                     chans, ptrs, _lib.stream_ptr(dev)), lib)
+    ref = F.conv2d(x.float(), wt[:tot].float().view(tot, cin, 1, 1), bias[:tot])
+    c0 = 0
+    for o, c in zip(outs, heads):
+        r = ref[:, c0:c0 + c]
+        assert ((o - r).abs().max() / r.abs().max()).item() <= 2e-5
+        c0 += c
+
+
 def test_conv3x3_tiled_repeated_full_size(dev):
     """The 160x160 256->256 layer of the network at bs8 (1 600 workgroups, two per CU): 20 launches on rotating inputs, every
     output equal to the first launch of its input (no race between the DMA ring, the barriers and the fragment reads under
