@@ -288,8 +288,8 @@ int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias
 /* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
  * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
  * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.
- * og_conv3x3s2_tiled_supported(N, Hin, Win, Cin, Cout): needs Hin, Win even, an output of 8k x 16k pixels, Cout % 128 == 0,
- * Cin % 64 == 0. */
+ * og_conv3x3s2_tiled_supported(N, Hin, Win, Cin, Cout): 0 = not served; needs Hin, Win even, Cout % 128 == 0, Cin % 64 == 0 and
+ * an output of 8k x 16k pixels (1: 16 x 8 output tiles) or 40 wide with an even height (2: 40 x 2 tiles, the 80 -> 40 level). */
 int og_conv3x3s2_tiled_supported(int N, int Hin, int Win, int Cin, int Cout);
 int og_conv3x3s2_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
                             int Win, int Cin, int Cout, int relu, void *stream);

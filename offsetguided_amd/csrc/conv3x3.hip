@@ -1078,12 +1078,13 @@ OG_API int OG_LP_NAME(og_conv2d_proj)(const void *x, const void *w_cat, const fl
 
 // ---- the tiled kernel (conv3x3_tiled.inc): pre-tiled weights, two workgroups per CU ----
 #ifndef OG_DT_F16
-// stride 2: H, W = INPUT size (even); served when the output is a multiple of 8 rows x 16 columns
+// stride 2: H, W = INPUT size (even); 1 = output a multiple of 8 rows x 16 columns, 2 = output 40 wide with an even height
 OG_API int og_conv3x3s2_tiled_supported(int N, int H, int W, int Cin, int Cout)
 {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (H & 1) || (W & 1)) return 0;
     if ((long)N * H * W * Cin >= (1l << 30) || (long)N * H * W * Cout >= (1l << 32)) return 0;
-    return (Cout % 128 == 0 && Cin % 64 == 0 && (H / 2) % 8 == 0 && (W / 2) % 16 == 0) ? 1 : 0;
+    if (Cout % 128 || Cin % 64) return 0;
+    return ((H / 2) % 8 == 0 && (W / 2) % 16 == 0) ? 1 : ((W / 2) == 40 && (H / 2) % 2 == 0) ? 2 : 0;
 }
 
 OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
@@ -1148,6 +1149,7 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         case 0: TILED_LAUNCH(16, 16, 4, 0); break;
         case 2: TILED_LAUNCH(16, 16, 4, 2); break;
         case 8: TILED_LAUNCH(16, 16, 4, 8); break;
+        case 10: TILED_LAUNCH(16, 16, 4, 10); break;
 #ifdef OG_TILED_ABLATIONS     // timing-only builds (wrong results): tools/build_variants.sh conv3x3.hip abl "-DOG_TILED_ABLATIONS"
         case 26: TILED_LAUNCH(16, 16, 4, 26); break;     // 10 + no DMA
         case 42: TILED_LAUNCH(16, 16, 4, 42); break;     // 10 + fragments read once
@@ -1156,13 +1158,19 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         case 122: TILED_LAUNCH(16, 16, 4, 122); break;   // MFMA only
         case 138: TILED_LAUNCH(16, 16, 4, 138); break;   // 10 + waits relaxed by one step
 #endif
-        default: TILED_LAUNCH(16, 16, 4, 10); break;   // weight-fragment prefetch + DMA issue behind the reads: measured best
+        // default: DMA issue behind the fragment reads.  (+ 8, the weight-fragment prefetch, is 1-3 % faster on the layer alone and
+        // no faster inside the network, for 14 more registers)
+        default: TILED_LAUNCH(16, 16, 4, 2); break;
         }
     } else {
-        switch (var) {
-        case 32: TILED_LAUNCH(20, 4, 1, 0); break;     // 80-pixel tiles: twice the workgroups
+        // OG_TILED_VAR40 (tuning phase): the 40-wide level: 0 / 2 = 40 x 4 tiles (160 pixels), 32 / 34 = 20 x 4 tiles (80 pixels: twice
+        // the workgroups), +2 = DMA issue behind the reads
+        const char *ve40 = getenv("OG_TILED_VAR40");
+        switch (ve40 ? atoi(ve40) : -1) {
+        case 32: TILED_LAUNCH(20, 4, 1, 0); break;
         case 34: TILED_LAUNCH(20, 4, 1, 2); break;
         case 0: TILED_LAUNCH(40, 4, 2, 0); break;
+        // default 40 x 4: the 20 x 4 tiles are 10 % faster on a layer alone (480 workgroups instead of 240), not inside the network
         default: TILED_LAUNCH(40, 4, 2, 2); break;
         }
     }
@@ -1180,8 +1188,9 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
     const int H = Hin / 2, W = Win / 2;
     const long M = (long)N * H * W, Min = (long)N * Hin * Win;
     OG_REQUIRE(Min * (long)Cin < (1l << 30) && M * (long)Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
-    OG_REQUIRE(Cout % 128 == 0 && Cin % 64 == 0 && H % 8 == 0 && W % 16 == 0, OG_EUNSUPPORTED,
-               "%s: needs Cout %% 128 == 0, Cin %% 64 == 0 and an output of 8k x 16k pixels (got %dx%d -> %dx%d, %d -> %d)", name,
+    const int kind = og_conv3x3s2_tiled_supported(N, Hin, Win, Cin, Cout);
+    OG_REQUIRE(kind != 0, OG_EUNSUPPORTED,
+               "%s: needs Cout %% 128 == 0, Cin %% 64 == 0 and an output of 8k x 16k pixels or 2k x 40 (got %dx%d -> %dx%d, %d -> %d)", name,
                Hin, Win, H, W, Cin, Cout);
     ConvArgs h = {};
     h.x = (const unsigned short *)x; h.w = (const unsigned short *)w_packed; h.bias = bias;
@@ -1193,17 +1202,19 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
     constexpr int lds_ = 3 * 128 * 64 + 3 * 3 * 4096;
     const char *ve = getenv("OG_TILED_S2_VAR");
     const int var = ve ? atoi(ve) : 0;
-    const long blocks = (long)N * (H / 8) * (W / 16) * h.n_tiles;
-#define S2_LAUNCH(VAR_)                                                                                               \
+#define S2_LAUNCH(TW_, TH_, WM_, VAR_)                                                                                \
     do {                                                                                                              \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
-            (void)hipFuncSetAttribute((const void *)conv3x3s2_tiled_kernel<16, 8, VAR_>,                              \
+            (void)hipFuncSetAttribute((const void *)conv3x3s2_tiled_kernel<TW_, TH_, WM_, VAR_>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                              \
-        hipLaunchKernelGGL((conv3x3s2_tiled_kernel<16, 8, VAR_>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, h); \
+        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
+        hipLaunchKernelGGL((conv3x3s2_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_,   \
+                           (hipStream_t)stream, h);                                                                   \
     } while (0)
-    if (ve && var == 0) S2_LAUNCH(0);
-    else S2_LAUNCH(2);       // DMA issue behind the fragment reads: measured 1-4 % faster
+    if (kind == 2) S2_LAUNCH(40, 2, 1, 2);
+    else if (ve && var == 0) S2_LAUNCH(16, 8, 2, 0);
+    else S2_LAUNCH(16, 8, 2, 2);       // DMA issue behind the fragment reads: measured 1-4 % faster
 #undef S2_LAUNCH
     OG_LAUNCH_CHECK(name);
     return OG_OK;

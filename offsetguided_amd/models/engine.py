@@ -85,6 +85,7 @@ BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fo
 # trunk ENTERS depth D (they only need the level's input): the trunk then descends through the large levels with the chip
 # to itself, and the bulk of the up1 branches runs beside the latency-bound 20x20 / 10x10 / 5x5 chain instead of before it.
 BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
+BRANCH_MIN_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MIN_DEPTH', '0'))   # levels above this depth run up1 in the trunk, unforked
 _pending_branches = []
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
@@ -308,7 +309,7 @@ class _Level:
         return _run(self.low3, low)
 
     def __call__(self, x):
-        if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
+        if BRANCHES and x.is_cuda and BRANCH_MIN_DEPTH <= self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None:
                 # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work

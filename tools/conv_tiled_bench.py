@@ -61,6 +61,7 @@ def main():
         for name, fn, var in arms:
             if var is not None:
                 os.environ['OG_TILED_VAR'] = str(var)      # read by the library at every call: fixed at graph capture
+                os.environ['OG_TILED_VAR40'] = str(var)
             for i in range(a.reps):
                 fn(i)
             torch.cuda.synchronize()
@@ -102,7 +103,7 @@ def main_s2():
     torch.backends.cudnn.benchmark = True
     cl = torch.channels_last
     dt = torch.bfloat16
-    for si, (n, h, w, cin, cout) in enumerate([(8, 320, 320, 128, 256), (8, 160, 160, 256, 256), (8, 64, 64, 256, 384)]):
+    for si, (n, h, w, cin, cout) in enumerate([(8, 320, 320, 128, 256), (8, 160, 160, 256, 256), (8, 80, 80, 256, 384)]):
         xs = [torch.randn(n, cin, h, w, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
         wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
         bias = torch.randn(cout, device=dev) * 0.1
