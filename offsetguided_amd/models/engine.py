@@ -85,6 +85,11 @@ BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fo
 # trunk ENTERS depth D (they only need the level's input): the trunk then descends through the large levels with the chip
 # to itself, and the bulk of the up1 branches runs beside the latency-bound 20x20 / 10x10 / 5x5 chain instead of before it.
 BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
+# OG_ENGINE_SIDE_SHARED = D: the up1 branches of the levels above depth D share ONE side stream (they run one after the other,
+# each with the chip's bulk share to itself, beside the trunk) instead of a stream each; with OG_ENGINE_BRANCH_DELAY they are
+# submitted deepest level first, the order in which the trunk joins them on its way up.
+SIDE_SHARED = int(os.environ.get('OG_ENGINE_SIDE_SHARED', '0'))
+_shared_side = {}
 BRANCH_MIN_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MIN_DEPTH', '0'))   # levels above this depth run up1 in the trunk, unforked
 _pending_branches = []
 _conv_ws = {}
@@ -314,7 +319,13 @@ class _Level:
             if self._side is None:
                 # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work
                 prio = int(os.environ.get('OG_ENGINE_SIDE_PRIORITY', '0'))
-                self._side = torch.cuda.Stream(x.device, priority=prio)
+                if self.depth < SIDE_SHARED:
+                    key = (x.device.index, _issuer.engine)
+                    if key not in _shared_side:
+                        _shared_side[key] = torch.cuda.Stream(x.device, priority=prio)
+                    self._side = _shared_side[key]
+                else:
+                    self._side = torch.cuda.Stream(x.device, priority=prio)
             box = {}
 
             def start(side=self._side, depth=self.depth, box=box):
@@ -324,18 +335,24 @@ class _Level:
                     _issuer.branch = depth + 1
                     box['up'] = _run(self.up1, x)
                     _issuer.branch = outer
+                    if depth < SIDE_SHARED:
+                        box['done'] = torch.cuda.Event()
+                        box['done'].record(side)
 
             if self.depth < BRANCH_DELAY:
                 _pending_branches.append(start)               # started when the trunk enters depth BRANCH_DELAY
             else:
-                while _pending_branches:
-                    _pending_branches.pop(0)()
+                while _pending_branches:                      # (shared stream: deepest first = the order of the joins)
+                    _pending_branches.pop(-1 if SIDE_SHARED else 0)()
                 start()
             low = self._lower(x)
             while 'up' not in box:                            # (a delay deeper than the pyramid: start before the join)
                 _pending_branches.pop(0)()
             up = box['up']
-            cur.wait_stream(self._side)                      # join before the merge
+            if 'done' in box:
+                cur.wait_event(box['done'])                  # shared side stream: only this level's branch
+            else:
+                cur.wait_stream(self._side)                  # join before the merge
         else:
             low = self._lower(x)
             up = _run(self.up1, x)

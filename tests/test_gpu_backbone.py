@@ -431,57 +431,78 @@ def test_conv3x3_rejects_bad_arguments(dev):
     assert lib.og_conv3x3_workspace_bytes(16, 48, 64) == 0
 
 
-def test_engine_matches_eager_fp32(dev):
+# engine vs the eager fp32 module, per arithmetic: relative to the largest reference value of the head
+ENGINE_GATES = {torch.float32: 1e-3, torch.float16: 5e-3, torch.bfloat16: 3e-2}
+
+
+def _bench_model(seed, dev):
+    """model_factory + bench_init (variance-preserving random weights) with the heads at their real magnitude."""
     import bench
     p = argparse.ArgumentParser()
     models.net_cli(p)
     model, _ = models.model_factory(p.parse_args(['--no-pretrain']))
-    bench.bench_init(model, 7)
+    bench.bench_init(model, seed)
     for head in model.headnets:                      # undo bench_init's head shrink: compare real magnitudes
         for m in head.modules():
             if isinstance(m, torch.nn.Conv2d):
                 m.weight.data.mul_(1e4)
+    return model.to(dev).eval()
+
+
+def _check_heads(ref, out, dtype, tag):
+    for h in (0, 1):
+        r, o = ref[h][0][-1].float(), out[h][0][-1]
+        assert o.dtype == torch.float32 and o.is_contiguous() and o.shape == r.shape
+        err = (o - r).abs().max().item() / r.abs().max().item()
+        print(f'{tag} head {h} {dtype}: relative error {err:.2e}')
+        assert err <= ENGINE_GATES[dtype], f"{tag} head {h} {dtype}: relative error {err}"
+
+
+def test_engine_matches_eager_fp32(dev):
+    model = _bench_model(7, dev)
     x = torch.randn(2, 3, 128, 128, device=dev)
-    model = model.to(dev).eval()
     with torch.no_grad():
         ref = model(x)
-    for use_graph in (False, True):
-        eng = models.InferenceEngine(model, 2, 128, 128, device=dev, use_graph=use_graph)
-        out = eng(x)
-        for h in (0, 1):
-            r, o = ref[h][0][-1].float(), out[h][0][-1]
-            assert o.dtype == torch.float32 and o.is_contiguous() and o.shape == r.shape
-            err = (o - r).abs().max().item() / r.abs().max().item()
-            assert err < 0.05, f"head {h}: relative error {err}"
-        assert out[0][0][0] is None and out[0][1] == [[], []]     # reference nesting, unused stack skipped
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        for use_graph in (False, True):
+            eng = models.InferenceEngine(model, 2, 128, 128, device=dev, dtype=dtype, use_graph=use_graph)
+            out = eng(x)
+            _check_heads(ref, out, dtype, f'128x128 graph={use_graph}')
+            assert out[0][0][0] is None and out[0][1] == [[], []]     # reference nesting, unused stack skipped
 
 
 @pytest.mark.parametrize("batch,height,width", [(3, 256, 384), (2, 256, 640), (1, 640, 640), (5, 384, 512)])
 def test_engine_other_shapes_match_eager(dev, batch, height, width):
-    """Non-square inputs route the layers through every conv path (halo 16x16 and 40x4 tiles, split-K,
-    MIOpen) and the forked up1 branches; compared with the eager fp32 module on the same weights."""
-    import bench
-    p = argparse.ArgumentParser()
-    models.net_cli(p)
-    model, _ = models.model_factory(p.parse_args(['--no-pretrain']))
-    bench.bench_init(model, 11)
-    for head in model.headnets:
-        for m in head.modules():
-            if isinstance(m, torch.nn.Conv2d):
-                m.weight.data.mul_(1e4)
+    """Non-square inputs route the layers through every conv path (tiled 16x16 / 40-wide tiles, stride 2, pointwise, split-K)
+    and the forked up1 branches; compared with the eager fp32 module on the same weights."""
+    model = _bench_model(11, dev)
     x = torch.randn(batch, 3, height, width, device=dev)
-    model = model.to(dev).eval()
     with torch.no_grad():
         ref = model(x)
-    eng = models.InferenceEngine(model, batch, height, width, device=dev)
-    out = eng(x)
-    out2 = eng(x)                                             # graph replay: same buffers, same result
-    for h in (0, 1):
-        r, o = ref[h][0][-1].float(), out[h][0][-1]
-        assert o.shape == r.shape
-        err = (o - r).abs().max().item() / r.abs().max().item()
-        assert err < 0.05, f"head {h}: relative error {err}"
-        assert torch.equal(o, out2[h][0][-1])
+    for dtype in (torch.bfloat16, torch.float16):
+        eng = models.InferenceEngine(model, batch, height, width, device=dev, dtype=dtype)
+        out = eng(x)
+        out2 = eng(x)                                             # graph replay: same buffers, same result
+        _check_heads(ref, out, dtype, f'{batch}x{height}x{width}')
+        for h in (0, 1):
+            assert torch.equal(out[h][0][-1], out2[h][0][-1])
+
+
+def test_engine_bench_shape_matches_eager(dev):
+    """THE benchmarked configuration -- bs8 640x640 through the HIP-graph engine, bench_init weights (heads un-shrunk) -- vs the
+    eager fp32 module at that shape (models/networks.py:189-194), both arithmetics."""
+    model = _bench_model(1234, dev)
+    x = torch.randn(8, 3, 640, 640, device=dev, generator=torch.Generator(dev).manual_seed(0))
+    with torch.no_grad():
+        ref = model(x)
+    ref = [[[None, ref[0][0][-1].clone()]], [[None, ref[1][0][-1].clone()]]]
+    torch.cuda.empty_cache()
+    for dtype in (torch.bfloat16, torch.float16):
+        eng = models.InferenceEngine(model, 8, 640, 640, device=dev, dtype=dtype)
+        out = eng(x)
+        _check_heads(ref, out, dtype, 'bs8 640x640')
+        del eng
+        torch.cuda.empty_cache()
 
 
 def test_engine_scale_head(dev):
@@ -506,7 +527,7 @@ def test_engine_scale_head(dev):
 
 def test_engine_matches_reference_golden(dev):
     """The reference model's outputs on key-seeded weights (tests/golden/backbone128.npz, generated from the imported
-    reference) vs the GPU engine: fp32 engine <= 1e-3 relative, bf16 engine reported and loosely gated."""
+    reference) vs the GPU engine: fp32 engine <= 1e-3 relative, bf16 engine <= 3e-2 (1.5-1.9e-2 measured)."""
     import os
     import numpy as np
     from offsetguided_amd import synth
@@ -519,7 +540,7 @@ def test_engine_matches_reference_golden(dev):
     model.load_state_dict(key_seeded_state(model.state_dict()))
     model = model.to(dev).eval()
     x = torch.from_numpy(synth.noise_batch(int(g['input_seed']), (1, 3, 128, 128))).to(dev)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 0.08)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 0.03)):
         eng = models.InferenceEngine(model, 1, 128, 128, device=dev, dtype=dtype, use_graph=False)
         out = eng(x)
         for h, name in ((0, 'hm'), (1, 'off')):
