@@ -832,17 +832,21 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps
             if (sps >= 4 && last >= p.stages - 1 && last >= 1) best = ks;
         }
     if (M >= 2048 && max_ks > 1 && !e) {   // 20x20 at bs8 (tuning knob: OG_CONV_MID_PLAN="bm,ksplit,stages")
-        int mb = 64, mk = 3, ms = 4;
-        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d,%d", &mb, &mk, &ms);
-        const bool bm_ok = mb == 64 || (mb == 128 && Cout % 128 == 0);
+        // default: 128 x 64 tiles (6 fragment reads per 16 MFMA instead of 8 per 8), 3 K splits, 3 stages = 450 workgroups of
+        // 72 KiB at batch 8: 24.7 us against 29.0 for 64 x 64 x 3 splits (tools/mid_plan_sweep.sh)
+        int mb = 128, mk = 3, ms = 3, mn = 64;      // "bm,ksplit,stages[,bn]": bn 64 with bm 128 = the rectangular tile
+        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d,%d,%d", &mb, &mk, &ms, &mn);
+        const bool rect = mb == 128 && mn == 64;
+        const bool bm_ok = mb == 64 || rect || (mb == 128 && Cout % 128 == 0);
         if (bm_ok && mk >= 1 && mk <= 3 && (ms == 3 || ms == 4 || (ms == 2 && mb == 64)) && (steps + mk - 1) / mk >= 4) {
             const int sps = (steps + mk - 1) / mk, last = steps - (mk - 1) * sps;
             if (last >= ms - 1 && (steps % mk == 0 || extra_steps)) {
                 best = mk;
                 p.stages = ms;
                 p.bm = p.bn = mb;
+                if (rect) p.bn = 64;
                 p.m_tiles = (int)((M + mb - 1) / mb);
-                p.n_tiles = Cout / mb;
+                p.n_tiles = Cout / p.bn;
             }
         }
     }
@@ -855,6 +859,7 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps
     // form lost at 20x20, 39.9 vs 34.2: slab bytes per last arriver decide.)
     p.in_launch = 1;
     if (const char *r = getenv("OG_CONV_REDUCE")) p.in_launch = atoi(r);
+    if (p.bm != p.bn) p.in_launch = 1;      // the finish kernel exists for the square tiles only
     return true;
 }
 
@@ -1033,7 +1038,13 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
         hipLaunchKernelGGL((conv3x3_kernel<BM_, BM_, ST_>), grid, dim3(256), lds_, st, a);                      \
     } while (0)
-    if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);
+    if (p.bm == 128 && p.bn == 64) {
+        constexpr int lds_ = 3 * (128 + 64) * 128;
+        static OgAttrOnce attr_;
+        if (attr_.need())
+            (void)hipFuncSetAttribute((const void *)conv3x3_kernel<128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+        hipLaunchKernelGGL((conv3x3_kernel<128, 64, 3>), grid, dim3(256), lds_, st, a);
+    } else if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);
     else if (p.bm == 128) CONV_LAUNCH(128, 3);
     else if (p.stages == 8) CONV_LAUNCH(64, 8);
     else if (p.stages == 3) CONV_LAUNCH(64, 3);
@@ -1128,16 +1139,17 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
     h.x_bytes = (int)(M * Cin * 2);
     h.w_bytes = Cout * 9 * Cin * 2;
     hipStream_t st = (hipStream_t)stream;
-#define TILED_LAUNCH(TW_, TH_, WM_, VAR_)                                                                             \
+#define TILED_LAUNCH(TW_, TH_, WM_, VAR_) TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, 4)
+#define TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, NW_)                                                                     \
     do {                                                                                                              \
-        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 5 + 255) / 256;                                                 \
-        const int lds_ = 2 * npa_ * 4096 + 3 * 128 * 64 + lds_extra;                                                  \
+        constexpr int halo_ = ((TW_ + 2) * (TH_ + 2) * 5 * 16 + 1023) / 1024 * 1024;                                  \
+        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024 + lds_extra;                                                 \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
-            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>,                        \
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>,                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
-        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
+        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>), dim3((unsigned)blocks_), dim3(64 * NW_), lds_, st, h); \
     } while (0)
     // OG_TILED_LDS_EXTRA (experiment): bytes of LDS requested on top of the kernel's own: 16384 leaves one workgroup per CU
     static const int lds_extra = getenv("OG_TILED_LDS_EXTRA") ? atoi(getenv("OG_TILED_LDS_EXTRA")) : 0;
@@ -1150,6 +1162,8 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         case 2: TILED_LAUNCH(16, 16, 4, 2); break;
         case 8: TILED_LAUNCH(16, 16, 4, 8); break;
         case 10: TILED_LAUNCH(16, 16, 4, 10); break;
+        case 64: TILED_LAUNCH_NW(16, 16, 4, 0, 8); break;    // 8 waves: 64 x 64 outputs per wave, four waves per SIMD
+        case 66: TILED_LAUNCH_NW(16, 16, 4, 2, 8); break;
 #ifdef OG_TILED_ABLATIONS     // timing-only builds (wrong results): tools/build_variants.sh conv3x3.hip abl "-DOG_TILED_ABLATIONS"
         case 26: TILED_LAUNCH(16, 16, 4, 26); break;     // 10 + no DMA
         case 42: TILED_LAUNCH(16, 16, 4, 42); break;     // 10 + fragments read once
@@ -1157,6 +1171,9 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         case 58: TILED_LAUNCH(16, 16, 4, 58); break;     // 10 + no DMA + fragments read once
         case 122: TILED_LAUNCH(16, 16, 4, 122); break;   // MFMA only
         case 138: TILED_LAUNCH(16, 16, 4, 138); break;   // 10 + waits relaxed by one step
+        case 258: TILED_LAUNCH(16, 16, 4, 258); break;   // 2 + weights always from the same two stages (L1 hits)
+        case 770: TILED_LAUNCH(16, 16, 4, 770); break;   // 2 + that + halo always chunk 0
+        case 18: TILED_LAUNCH(16, 16, 4, 18); break;     // 2 + no DMA
 #endif
         // default: DMA issue behind the fragment reads.  (+ 8, the weight-fragment prefetch, is 1-3 % faster on the layer alone and
         // no faster inside the network, for 14 more registers)
@@ -1175,6 +1192,7 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         }
     }
 #undef TILED_LAUNCH
+#undef TILED_LAUNCH_NW
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
