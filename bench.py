@@ -469,7 +469,12 @@ def cpu_baseline(a, model, maps, cd):
         oracle.decode(hm_np[:n_c], off_np[:n_c], cd.COCO_PERSON_SKELETON, **cflags)
     c_ms = (time.perf_counter() - t0) / n_c * 1e3
     per_img = bb_s * (2 if a.flip else 1) + dec_s / a.batch
+    # the spread over the individual runs (a 128-thread Pool on a shared host is noisy: the value moved 0.33 ... 0.54 between
+    # runs of rounds 2 and 3): images/s from the fastest and the slowest decoder / backbone run
+    d_runs, b_runs = getattr(rs.time_decoder, 'last_runs', [dec_s]), getattr(rs.time_backbone, 'last_runs', [bb_s])
+    rate = lambda b, d: 1.0 / (b * (2 if a.flip else 1) + d / a.batch)   # noqa: E731
     return {'value': round(1.0 / per_img, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'value_range': [round(rate(max(b_runs), max(d_runs)), 4), round(rate(min(b_runs), min(d_runs)), 4)],
             'port_of': 'decoder/factory.py:52-96 op for op (oracle/restatement.py: torch-CPU interpolate / pad + max_pool2d / topk / '
                        'gather, numpy grouping in a Pool(batch)) + eager fp32 models/networks.py:189-194',
             'sample': f'decoder: one batch of {a.batch} images, 1 warm-up + median of 5 ({dec_s * 1e3:.0f} ms/batch); backbone: '

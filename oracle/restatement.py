@@ -203,6 +203,7 @@ def time_decoder(hm_lr, off_lr, skeleton, flags, repeats=5):
             ts.append(time.perf_counter() - t0)
     finally:
         dec.close()
+    time_decoder.last_runs = [float(t) for t in ts]        # the individual runs: bench.py reports their spread
     return float(np.median(ts)), torch.get_num_threads()
 
 
@@ -221,4 +222,5 @@ def time_backbone(model, size=640, repeats=5, budget_s=60.0):
             ts.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start > budget_s and len(ts) >= 1:
                 break
+    time_backbone.last_runs = [float(t) for t in ts]
     return float(np.median(ts)), len(ts)
