@@ -338,7 +338,7 @@ def main():
 
             def conv_once(i):
                 _lib.check(lib.og_conv3x3_tiled_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
-                                                     _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, _lib.stream_ptr(dev)), lib)
+                                                     _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
             timed(conv_once, 5)
             conv_us = timed(conv_once, 30) * 1e3
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304

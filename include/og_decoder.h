@@ -271,9 +271,13 @@ size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout
 /* ---- the same 3x3 stride-1 convolution for the LARGE levels (160x160 / 80x80 / 40x40 at 640x640 input), on weights tiled
  * once in advance: csrc/conv3x3_tiled.inc -- halo-tiled direct convolution, two 4-wave workgroups per CU, 32-channel K steps,
  * every weight stage one contiguous 8 KiB LDS image.  Same arithmetic and epilogue as og_conv3x3_bf16 (fp32 accumulation, the
- * residual initialises the accumulators, one rounding), no workspace.
- *   og_conv3x3_tiled_supported: 0 = shape not served (needs Cout % 128 == 0, Cin % 64 == 0, and H, W multiples of 16 or
- *     W == 40 with H % 4 == 0), otherwise the tile kind.
+ * residual initialises the accumulators, one rounding).
+ *   og_conv3x3_tiled_supported: 0 = shape not served (needs Cout % 128 == 0, Cin % 64 == 0, and H, W multiples of 16, or
+ *     W == 40 / W == 20 with H % 4 == 0), otherwise the tile kind (16 x 16, 40 x 4, 20 x 4 pixels).
+ *   og_conv3x3_tiled_workspace_bytes: 0 for most shapes (workspace may then be NULL).  A level whose output tiles alone would
+ *     not fill the chip (40 x 40 and 20 x 20 at batch 8) is also split along K over 2-3 workgroups per tile, which meet through
+ *     fp32 slabs + arrival tickets in the workspace: 256-byte aligned, ZERO-INITIALISED once by the caller, reusable by any
+ *     later call on the same stream.
  *   og_conv3x3_pack_w16: w (Cout,3,3,Cin) 16-bit (bf16 or fp16 alike) -> packed, the same number of bytes, laid out
  *     [Cout/128][Cin/32][9 taps][128 rows x 64 B] with the k order / slot swizzle the kernel's fragment reads expect;
  *     order 0 = taps in their own order (for og_conv3x3_tiled_*), order 1 = the order the stride-2 kernel consumes them
@@ -283,8 +287,9 @@ size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout
  *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
 int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout);
 int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream);
+size_t og_conv3x3_tiled_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
-                          int W, int Cin, int Cout, int relu, void *stream);
+                          int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 /* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
  * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
  * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.
@@ -323,7 +328,7 @@ int og_stem7x7_f16(const float *images, const void *w_packed, const float *bias,
 int og_conv3x3_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
                    int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv3x3_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
-                         int W, int Cin, int Cout, int relu, void *stream);
+                         int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv3x3s2_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
                            int Win, int Cin, int Cout, int relu, void *stream);
 int og_conv1x1_tiled_f16(const void *x1, int C1, int H1, int W1, int stride1, const void *x2, int C2, int H2, int W2, int stride2,

@@ -92,6 +92,20 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 }
 constexpr uint32_t kOobOffset = 0x80000000u;  // beyond any tensor this library accepts (< 2 GiB)
 
+// 16-byte write-through (sc1) buffer store with a scalar offset.  HAZARD (gfx950, ROCm 7.2): hipcc pads a VALU write of the
+// data registers of a > 8-byte buffer store only when the store's soffset is NOT an SGPR (LLVM's createsVALUHazard); with an
+// SGPR soffset the next instruction may be a VALU write of those registers -- seen in the K-split slab stores: `buffer_store_
+// dwordx4 v[14:17], ..., s16 offen sc1` directly followed by `v_add_u32 v14, ...` -- and the hardware then stores the NEW v14
+// for the last four lanes of every 16-lane group (one slab dword per pixel wrong in ~1 of 3 launches).  Two wait states behind
+// every such store close it (cdna_hip_programming.md 5.7: the same rule as for inline-asm x3 / x4 stores); the asm store is
+// not counted by the compiler: every caller drains it with an explicit `s_waitcnt vmcnt(0)` before the ticket.
+__device__ __forceinline__ void store_b128_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v)
+{
+    // store and wait states in ONE asm statement: as separate statements hipcc schedules the next address computation
+    // (`v_add_u32 v14, ...`, a write of the just-stored register) between them
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0()
 {
@@ -375,8 +389,7 @@ conv3x3_kernel(ConvArgs a)
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), tile_slabs,
-                                                       (n * MT + m) * 4096 + tid * 16, own_off, 16);
+                store_b128_sc1(tile_slabs, (n * MT + m) * 4096 + tid * 16, own_off, acc[n][m]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int *flag = reinterpret_cast<int *>(lds);
@@ -727,8 +740,8 @@ conv3x3_halo_kernel(ConvArgs a)
                 const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + cur.n0 + cg * 8;
                 const u16x8 v = *reinterpret_cast<const u16x8 *>(base + (px - px0) * kOPitch + cg * 16);
                 // Write-through keeps the Infinity Cache free of DIRTY activations (OG_CONV_STORE; measured: no difference)
-                if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a.out + off), "v"(v) : "memory");
-                else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a.out + off), "v"(v) : "memory");
+                if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a.out + off), "v"(v) : "memory");
+                else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(a.out + off), "v"(v) : "memory");
                 else *reinterpret_cast<u16x8 *>(a.out + off) = v;
             }
         };
@@ -1105,6 +1118,17 @@ OG_API int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout)
     return tiled_kind(H, W, Cin, Cout);
 }
 
+// 0 when the launch needs no K split; otherwise [zero page 256 B | tickets | fp32 slabs], zero-initialised once by the caller
+OG_API size_t og_conv3x3_tiled_workspace_bytes(int N, int H, int W, int Cin, int Cout)
+{
+    const int kind = og_conv3x3_tiled_supported(N, H, W, Cin, Cout);
+    if (!kind) return 0;
+    const long items = tiled_items(kind, N, H, W, Cout);
+    const int ks = tiled_ksplit(kind, items, Cin);
+    if (ks <= 1 || items > (long)kMaxTiles) return 0;
+    return kZeroPageBytes + kMaxTiles * sizeof(int) + (size_t)items * ks * tiled_slab_bytes(kind);
+}
+
 OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream)
 {
     OG_REQUIRE(order >= 0 && order <= 3, OG_EINVAL,
@@ -1121,7 +1145,8 @@ OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void
 #endif
 
 OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N,
-                                        int H, int W, int Cin, int Cout, int relu, void *stream)
+                                        int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes,
+                                        void *stream)
 {
     const char *name = OG_LP_STR("og_conv3x3_tiled");
     OG_REQUIRE(x && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
@@ -1139,6 +1164,16 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
     h.x_bytes = (int)(M * Cin * 2);
     h.w_bytes = Cout * 9 * Cin * 2;
     hipStream_t st = (hipStream_t)stream;
+    const long items = tiled_items(kind, N, H, W, Cout);
+    h.ksplit = (items <= (long)kMaxTiles) ? tiled_ksplit(kind, items, Cin) : 1;
+    if (h.ksplit > 1) {
+        const size_t need = kZeroPageBytes + kMaxTiles * sizeof(int) + (size_t)items * h.ksplit * tiled_slab_bytes(kind);
+        OG_REQUIRE(workspace && workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu bytes (og_conv3x3_tiled_workspace_bytes)", name,
+                   workspace ? workspace_bytes : (size_t)0, need);
+        OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
+        h.counters = (int *)((char *)workspace + kZeroPageBytes);
+        h.partial = (float *)((char *)workspace + kZeroPageBytes + kMaxTiles * sizeof(int));
+    }
 #define TILED_LAUNCH(TW_, TH_, WM_, VAR_) TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, 4)
 #define TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, NW_)                                                                     \
     do {                                                                                                              \
@@ -1148,7 +1183,7 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         if (attr_.need())                                                                                             \
             (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>,                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                             \
+        const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles * h.ksplit;                                  \
         hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>), dim3((unsigned)blocks_), dim3(64 * NW_), lds_, st, h); \
     } while (0)
     // OG_TILED_LDS_EXTRA (experiment): bytes of LDS requested on top of the kernel's own: 16384 leaves one workgroup per CU
@@ -1179,6 +1214,8 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
         // no faster inside the network, for 14 more registers)
         default: TILED_LAUNCH(16, 16, 4, 2); break;
         }
+    } else if (kind == 3) {
+        TILED_LAUNCH(20, 4, 1, 2);
     } else {
         // OG_TILED_VAR40 (tuning phase): the 40-wide level: 0 / 2 = 40 x 4 tiles (160 pixels), 32 / 34 = 20 x 4 tiles (80 pixels: twice
         // the workgroups), +2 = DMA issue behind the reads

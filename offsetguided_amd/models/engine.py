@@ -75,6 +75,9 @@ CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192
 CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))   # bit 0: 3x3 stride 1, bit 1: 3x3 stride 2 (og_conv3x3s2_tiled_*), bit 2: 1x1
 # bit 2 (4): pointwise layers of the large levels (junction, projection skips, heads) on og_conv1x1_tiled_* / og_conv1x1_heads_*
 CONV_PW_MIN_PIXELS = int(os.environ.get('OG_CONV_PW_MIN_PIXELS', '8192'))
+# 3x3 stride-1 layers with at least this many output pixels go to the tiled kernel where it serves the shape (20x20 at batch 8
+# = 3 200 pixels: 20 x 4 tiles split 3 ways along K)
+CONV_TILED_MIN_PIXELS = int(os.environ.get('OG_CONV_TILED_MIN_PIXELS', '2048'))
 CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
@@ -164,6 +167,9 @@ class _Conv:
             pixels = n * ((h - 1) // st + 1) * ((w - 1) // st + 1)
             # stride 2: the split-K kernel wins where M is small (40x40 -> 20x20 and below at bs8: 30 / 15 / 12 us against
             # MIOpen + epilogue 48 / 30 / 26); the large stride-2 layers stay on MIOpen (CK is 1.2-1.6x faster there)
+            if (st == 1 and (CONV_TILED & 1) and pixels >= CONV_TILED_MIN_PIXELS and self.w.shape[0] % 128 == 0
+                    and _lib.load().og_conv3x3_tiled_supported(n, h, w, c, self.w.shape[0])):
+                return self._hip(x, skip)
             if pixels <= (CONV_S2_MAX_PIXELS if st == 2 else CONV3X3_MAX_PIXELS) or (st == 1 and (
                     pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
                     and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
@@ -230,15 +236,18 @@ class _Conv:
         lib = _lib.load()
         out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
                           memory_format=torch.channels_last)
-        if ((CONV_TILED & 1) and st == 1 and n * h * w >= CONV3X3_HALO_MIN_PIXELS
+        if ((CONV_TILED & 1) and st == 1 and n * h * w >= CONV_TILED_MIN_PIXELS
                 and lib.og_conv3x3_tiled_supported(n, h, w, c, cout)):
             if self.w_tiled is None:     # tiled once, during the warm-up passes (never inside graph capture)
                 assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
                 self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
                 _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 0, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+            need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, cout)      # K-split levels: tickets + fp32 slabs
+            ws = _conv3x3_workspace(x.device, need) if need else None
             _lib.check(_lib.lp(lib, 'og_conv3x3_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
                                                                _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w,
-                                                               c, cout, int(self.relu), _lib.stream_ptr(x.device)), lib)
+                                                               c, cout, int(self.relu), _lib.ptr(ws) if need else None,
+                                                               ws.numel() if need else 0, _lib.stream_ptr(x.device)), lib)
             return out
         ws = _conv3x3_workspace(x.device, lib.og_conv2d_workspace_bytes(n, h, w, c, cout, 3, st))
         _lib.check(_lib.lp(lib, 'og_conv2d', x.dtype)(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),

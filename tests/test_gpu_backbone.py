@@ -203,7 +203,9 @@ def test_conv3x3_halo_kernel_matches_torch(dev, shape, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 32, 128, 128), (1, 48, 32, 192, 256), (2, 80, 80, 256, 256),
-                                   (1, 4, 40, 64, 128), (2, 40, 40, 384, 384), (1, 12, 40, 128, 256), (3, 16, 32, 64, 384)])
+                                   (1, 4, 40, 64, 128), (2, 40, 40, 384, 384), (1, 12, 40, 128, 256), (3, 16, 32, 64, 384),
+                                   (8, 40, 40, 384, 384), (8, 20, 20, 384, 384), (2, 20, 20, 256, 128), (8, 40, 40, 256, 256),
+                                   (1, 8, 20, 128, 256)])
 def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
     """og_conv3x3_tiled_* (csrc/conv3x3_tiled.inc: two 4-wave workgroups per CU, pre-tiled weights, 32-channel K steps) vs an
     fp32 torch convolution of the same 16-bit operands, with and without the residual / ReLU epilogue; bit-identical
@@ -223,6 +225,8 @@ def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
     assert torch.equal(packed.view(torch.int16).sort().values, wt.reshape(-1).view(torch.int16).sort().values)
     fn = _lib.lp(lib, 'og_conv3x3_tiled', dtype)
     tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, cin, cout)       # > 0: the launch is split along K (few output tiles)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev) if need else None
     for use_skip, relu in ((True, 1), (False, 0)):
         ref = F.conv2d(x.float(), wt.float(), bias, 1, 1)
         ref = F.relu(ref + skip.float()) if use_skip else ref
@@ -230,7 +234,7 @@ def test_conv3x3_tiled_kernel_matches_torch(dev, shape, dtype):
         for _ in range(2):
             out = torch.full_like(skip, float('nan'))
             _lib.check(fn(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None, _lib.ptr(out),
-                          n, h, w, cin, cout, relu, _lib.stream_ptr(dev)), lib)
+                          n, h, w, cin, cout, relu, _lib.ptr(ws) if need else None, need, _lib.stream_ptr(dev)), lib)
             outs.append(out)
         err = ((outs[0].float() - ref).abs().max() / ref.abs().max()).item()
         assert err <= tol, f'relative error {err}'
@@ -370,7 +374,7 @@ def test_conv3x3_tiled_repeated_full_size(dev):
         i = it % 2
         out = torch.empty_like(xs[i])
         _lib.check(lib.og_conv3x3_tiled_bf16(_lib.ptr(xs[i]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(xs[1 - i]), _lib.ptr(out),
-                                             8, 160, 160, 256, 256, 1, _lib.stream_ptr(dev)), lib)
+                                             8, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
         if first[i] is None:
             first[i] = out
         else:

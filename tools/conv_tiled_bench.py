@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from offsetguided_amd import _lib  # noqa: E402
 
 SHAPES = [(8, 160, 160, 256, 256), (8, 80, 80, 256, 256), (8, 40, 40, 384, 384), (16, 160, 160, 256, 256),
-          (8, 40, 40, 384, 256), (8, 40, 40, 256, 256)]
+          (8, 40, 40, 384, 256), (8, 40, 40, 256, 256), (8, 20, 20, 384, 384)]
 
 
 def main():
@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16')
     ap.add_argument('--vars', type=int, nargs='*', default=[0], help='OG_TILED_VAR values to compare (tuning switches of the tiled kernel)')
     ap.add_argument('--no-halo', action='store_true', help='skip the first-generation kernel')
+    ap.add_argument('--ksplits', type=int, nargs='*', default=[], help='OG_TILED_KSPLIT values to compare (0 = the plan\'s own choice)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()
@@ -48,9 +49,12 @@ def main():
             _lib.check(old_fn(_lib.ptr(xs[i % 3]), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w, cin,
                               cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
 
+        # K-split workspace for ANY split the arms may force (allocated once: the captured graphs keep its address)
+        tws = torch.zeros(256 + 65536 + n * h * w * cout * 4 * 8, dtype=torch.uint8, device=dev)
+
         def new(i, o=1):
             _lib.check(new_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w,
-                              cin, cout, 1, _lib.stream_ptr(dev)), lib)
+                              cin, cout, 1, _lib.ptr(tws), tws.numel(), _lib.stream_ptr(dev)), lib)
 
         old(0)
         new(0)
@@ -58,7 +62,13 @@ def main():
         diff = (outs[0].float() - outs[1].float()).abs().max().item()
         graphs = {}
         arms = ([] if a.no_halo else [('halo', old, None)]) + [('tiled' + (f'/v{v}' if v else ''), new, v) for v in a.vars]
+        arms += [(f'tiled/ks{ks}', new, -ks - 1) for ks in a.ksplits]
         for name, fn, var in arms:
+            os.environ.pop('OG_TILED_KSPLIT', None)
+            if var is not None and var < 0:
+                if var != -1:
+                    os.environ['OG_TILED_KSPLIT'] = str(-var - 1)
+                var = 0
             if var is not None:
                 os.environ['OG_TILED_VAR'] = str(var)      # read by the library at every call: fixed at graph capture
                 os.environ['OG_TILED_VAR40'] = str(var)
