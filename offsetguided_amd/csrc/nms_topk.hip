@@ -44,6 +44,12 @@
 #ifdef OG_K1_STAMPS   // tuning harness: time points inside the limb pairing (value-dependent, so they cannot be hoisted)
 __device__ long long g_k1_stamps[1024 * 16];
 #define OG_COLLECT_STAMP(i, dep) do { if (threadIdx.x == 0 && g_k1_stamps[blockIdx.x * 16 + (i)] == 0 && (dep) == (dep)) g_k1_stamps[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+__device__ long long g_band_stamps[2048 * 8];   // band_topk_kernel / merge_collect_kernel: [workgroup][time point]
+#define BAND_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_band_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#define MERGE_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 900) g_band_stamps[(1100 + blockIdx.x) * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define BAND_STAMP(i) do { } while (0)
+#define MERGE_STAMP(i) do { } while (0)
 #endif
 #include "collect_body.h"
 #include "og_common.h"
@@ -371,40 +377,39 @@ struct WaveSeg {
 // FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
 // the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
 // One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
-// this the same number of times: it contains workgroup barriers).  `all` / `flt`: n_all = nbands * k keys each, in LDS;
+// this the same number of times: it contains workgroup barriers).  gk: the plane's `nlists` sorted lists of k keys each,
+// zero-padded by their writers (a key is never zero).  `all` / `flt`: n_all = nlists * k keys each, in LDS;
 // `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
 // SC1: the band lists were written in THIS launch by other workgroups (sc1 stores): read them with sc1 loads.
 template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit>
-__device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, const int *__restrict__ gc, uint64_t *all,
+__device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uint64_t *all,
                                             uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
-                                            const float *__restrict__ p, int H, int W, int k, int nbands, int t_sub, Emit &&emit)
+                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit)
 {
-    const int n_all = nbands * k, lane = tid & 63;
-    // keys and band counts are fetched together (one memory round trip), masked afterwards
-    if constexpr (SC1) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(gk), 0, n_all * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(gc), 0, nbands * 4, 0x00020000);
-        for (int i = tid; i < n_all; i += nthr) {
-            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(kr, i * 8, 0, 16);
-            const int c = __builtin_amdgcn_raw_buffer_load_b32(cr, (i / k) * 4, 0, 16);
-            all[i] = (i % k < c) ? (((uint64_t)t.y << 32) | t.x) : 0ull;
+    const int n_all = nlists * k, lane = tid & 63;
+    // All of a thread's keys are requested before the first one is used (one memory round trip, not one per key), and
+    // land in LDS rank-major -- all[rank * nlists + list] -- so that the subset of step A is the head of the array.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(gk), 0, n_all * 8, 0x00020000);
+    constexpr int U = 4;
+    for (int base = 0; base < n_all; base += U * nthr) {
+        u32x2 kk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)   // (indices past the end read as zero: buffer range check)
+            kk[u] = __builtin_amdgcn_raw_buffer_load_b64(kr, (base + u * nthr + tid) * 8, 0, SC1 ? 16 : 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * nthr + tid;
+            if (i < n_all) all[(i % k) * nlists + i / k] = ((uint64_t)kk[u].y << 32) | kk[u].x;
         }
-    } else
-    for (int i = tid; i < n_all; i += nthr) {
-        const uint64_t key = gk[i];
-        const int c = gc[i / k];
-        all[i] = (i % k < c) ? key : 0ull;
     }
     if (tid == 0) { *s_bound = 0ull; *s_nf = 0; }
     __syncthreads();
-    // A) k-th largest of the subset {first t_sub keys of each band}
-    const int n_sub = nbands * t_sub;
-    for (int i = tid; i < n_sub; i += nthr) flt[i] = all[(i / t_sub) * k + i % t_sub];
-    __syncthreads();
+    // A) k-th largest of the subset {first t_sub keys of each list}: a lower bound of the plane's k-th best
+    const int n_sub = nlists * t_sub;
     for (int i = tid; i < n_sub; i += nthr) {
-        const uint64_t mine = flt[i];
-        if (mine != 0ull && og_count_greater(flt, n_sub, mine) == k - 1) *s_bound = mine;
+        const uint64_t mine = all[i];
+        if (mine != 0ull && og_count_greater(all, n_sub, mine) == k - 1) *s_bound = mine;
     }
     __syncthreads();
     const uint64_t bound = *s_bound;
@@ -469,7 +474,7 @@ __global__ void __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_pe
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
                  int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
                  int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded, int helper,
-                 TailArgs tl)
+                 int wl, TailArgs tl)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
     // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
@@ -479,6 +484,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     int *s_slot = s_cnt + kMaxWaves;   // which of the 2*nwaves key buffers holds wave w's final list
     int *s_tau_p = s_slot + kMaxWaves;    // followed by the streaming-waves-done counter
 #define s_tau (*s_tau_p)
+    BAND_STAMP(0);
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
 #ifdef OG_K1_REVERSE_PLANES   // A/B: read first what K1a wrote last; measured no gain
@@ -584,7 +590,14 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                 if (pick != 0ull) bound = max(bound, __builtin_amdgcn_readlane(sv, __builtin_ctzll(pick)));
                 if (lane_id == 0 && bound > 1) atomicMax(&s_tau, bound);
                 if (done >= nstream) break;
-                __builtin_amdgcn_s_sleep(64);
+                // (the wait is cut into short naps: the streaming waves' epilogue may hold a workgroup barrier, and the
+                // launch ends with its last wave)
+                bool stop = false;
+                for (int nap = 0; nap < 8 && !stop; ++nap) {
+                    __builtin_amdgcn_s_sleep(8);
+                    stop = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= nstream;
+                }
+                if (stop) break;
             }
             // leave no vector-memory operation pending on this path: otherwise the compiler has to
             // assume unknown outstanding counts at the head of the streaming loop below and drains
@@ -592,10 +605,17 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
     }
-    auto iter_begin = [&](int) {
+    // A streaming wave reports itself done a few rows BEFORE its last one: the helper (whose bound could no longer save
+    // anything) then leaves ahead of the streaming waves instead of up to one polling period behind them.
+    bool reported = false;
+    auto iter_begin = [&](int r) {
         if (!NMS_MODE || !gslot) return;
         const int t = s_tau;  // LDS broadcast
         if (t > seg.tau_bits) seg.set_tau(__builtin_bit_cast(float, t));
+        if (!reported && (FUSED ? 4 * r : r) + 4 * PF >= g.r1) {
+            reported = true;
+            if (lane_id == 0) atomicAdd(s_done, 1);
+        }
     };
 
     auto emit_fn = [&](int row, const Px<VEC> &v, const Px<VEC> &ha, const Px<VEC> &hb, const Px<VEC> &hc) {
@@ -639,18 +659,32 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             }
         }
     };
+    BAND_STAMP(1);
     if (wave < nstream) {  // threshold refresh at the END of each iteration (see walk_panel)
         if constexpr (FUSED) walk_panel_fused<PF>(src, H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
         else walk_panel<VEC, PF>(src, g, emit_fn, NoHook(), iter_begin);
     }
-    if (gslot && lane_id == 0 && wave < nstream) atomicAdd(s_done, 1);
+    if (gslot && lane_id == 0 && wave < nstream && !reported) atomicAdd(s_done, 1);
     if ((hmode & 8) && hist_all && lane_id == 0 && wave < nstream) {  // debug: pushes / final threshold / waves, kept in the unused tail of the slot region
         int *dbg = hist_all + (size_t)(total / nbands) * kHistBins - 16;
         atomicAdd(dbg + 0, seg.npush); atomicMax(dbg + 1, seg.tau_bits); atomicAdd(dbg + 2, 1); atomicAdd(dbg + 3, seg.tau_bits > 1 ? 1 : 0);
     }
 
+    BAND_STAMP(2);
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
+    BAND_STAMP(3);
+    if (!TAIL && wl > 1) {
+        // one list per streaming wave (wl = streaming waves per band): no workgroup barrier, no cross-wave ranking here --
+        // the merge launch ranks the plane's nbands * wl sorted lists anyway.  The helper wave has no list.
+        if (wave < nstream) {
+            const size_t li = ((size_t)plane * nbands + band) * wl + wave;
+            const int c = min(seg.cnt, k);
+            for (int i = lane_id; i < k; i += 64) band_keys[li * k + i] = i < c ? seg.cur[i] : 0ull;   // zero-padded
+        }
+        BAND_STAMP(4);
+        return;
+    }
     if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_slot[wave] = (int)((seg.cur - smem) / cap); }
     __syncthreads();
     int total_keys = 0;
@@ -675,15 +709,20 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             }
         }
     }
-    if constexpr (!TAIL) {
-        if (threadIdx.x == 0) band_cnt[(size_t)plane * nbands + band] = min(total_keys, k);
-    } else {
+    for (int t = min(total_keys, k) + threadIdx.x; t < k; t += blockDim.x) {   // the list is zero-padded to k keys
+        if constexpr (TAIL) {
+            u32x2 v;
+            v.x = 0u;
+            v.y = 0u;
+            __builtin_amdgcn_raw_buffer_store_b64(v, okr, t * 8, 0, 16);
+        } else {
+            out[t] = 0ull;
+        }
+    }
+    BAND_STAMP(4);
+    if constexpr (TAIL) {
         const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
         int *s_flag = s_cnt;   // the per-wave counts are not needed any more
-        if (tid == 0) {
-            const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(band_cnt + (size_t)plane * nbands, 0, nbands * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(min(total_keys, k), cr, band * 4, 0, 16);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -708,7 +747,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         int64_t *oi = tl.out_inds + (size_t)plane * k;
         const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(os, 0, k * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(oi, 0, k * 8, 0x00020000);
-        merge_plane<true, false, true>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, all, flt, s_bound,
+        merge_plane<true, false, true>(band_keys + (size_t)plane * n_all, all, flt, s_bound,
                                        s_nf, tid, nthr, in + (size_t)plane * H * W, H, W, k, nbands, tl.t_sub,
                                        [&](int rank, float v, long idx) {
                                            u32x2 w;
@@ -790,12 +829,12 @@ template <bool NMS_MODE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
                    int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
-                   const float *__restrict__ in, int H, int W, int k, int nbands, int t_sub,
+                   const float *__restrict__ in, int H, int W, int k, int nbands, int nlists, int t_sub,
                    float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const int plane = blockIdx.x, tid = threadIdx.x;
-    const int n_all = nbands * k;
+    const int n_all = nlists * k;
     __shared__ uint64_t s_bound;
     __shared__ int s_nf;
     float *os = out_scores + (size_t)plane * k;
@@ -803,9 +842,9 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
     if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
         for (int i = tid; i < nbands; i += blockDim.x) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
     if (blockIdx.x == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
-    merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, lds64, lds64 + n_all,
+    merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)plane * n_all, lds64, lds64 + n_all,
                                  &s_bound, &s_nf, tid, 256,
-                                 in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W), H, W, k, nbands,
+                                 in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W), H, W, k, nlists,
                                  t_sub, [&](int rank, float v, long idx) { os[rank] = v; oi[rank] = (int64_t)idx; });
 }
 
@@ -818,12 +857,13 @@ template <int ND>
 __global__ void __launch_bounds__(512)
 merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt, int *__restrict__ hist_all,
                      uint64_t *__restrict__ ws_magic, uint64_t magic, const float *__restrict__ in, int planes, int nbands,
-                     int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
+                     int nlists, int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint64_t s_bound[2];
     __shared__ int s_nf[2];
-    const int k = a.K, H = a.H, W = a.W, n_all = nbands * k, Kp = (k + 3) & ~3;
+    MERGE_STAMP(0);
+    const int k = a.K, H = a.H, W = a.W, n_all = nlists * k, Kp = (k + 3) & ~3;
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
     uint64_t *all = lds64 + (size_t)half * 2 * n_all, *flt = all + n_all;
     float *ls = reinterpret_cast<float *>(lds64 + 4 * (size_t)n_all);   // [2][Kp] scores | [2][Kp] indices | pairing scratch
@@ -847,15 +887,17 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restri
     float *os = limb ? ls + half * Kp : out_scores + (size_t)plane * k;
     int *oi32 = li + half * Kp;
     int64_t *oi64 = out_inds + (size_t)plane * k;
-    merge_plane<true, false>(band_keys + (size_t)plane * n_all, band_cnt + (size_t)plane * nbands, all, flt, &s_bound[half],
-                             &s_nf[half], tid, 256, in + (size_t)plane * H * W, H, W, k, nbands, t_sub,
+    merge_plane<true, false>(band_keys + (size_t)plane * n_all, all, flt, &s_bound[half],
+                             &s_nf[half], tid, 256, in + (size_t)plane * H * W, H, W, k, nlists, t_sub,
                              [&](int rank, float v, long idx) {
                                  if (limb) { os[rank] = v; oi32[rank] = (int)idx; }
                                  else if (live) { os[rank] = v; oi64[rank] = (int64_t)idx; }
                              });
     if (!limb) return;
     __syncthreads();
+    MERGE_STAMP(1);
     if (threadIdx.x < 64) og_collect::limb_rows<ND, int>(a, n, l, threadIdx.x, ls, li, ls + Kp, li + Kp, sm);
+    MERGE_STAMP(2);
 }
 
 // dynamic LDS the tail of band_topk_kernel<..., TAIL> needs (see its carve-up), for a workgroup of `waves` waves
@@ -867,6 +909,7 @@ size_t band_tail_lds_bytes(int nbands, int k, int L, int waves)
 
 struct Plan {
     int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;
+    int wl, nlists;   // sorted k-lists a band hands to the merge: one (cross-wave ranking in the band kernel) or one per streaming wave
     size_t keys_off, cnt_off, hist_off, magic_off, bytes;
     uint64_t magic;
 };
@@ -891,16 +934,22 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     p->nbands = (H + rows - 1) / rows;
     p->cap = (2 * k + 64 + 63) / 64 * 64;
     if ((size_t)p->nwaves * 2 * p->cap * sizeof(uint64_t) > 60 * 1024) return false;
-    // subset depth for the merge's lower bound: nbands * t_sub >= k whenever possible
-    p->t_sub = min(k, max(2, (k + p->nbands - 1) / p->nbands + 1));
+    // One list per streaming wave when the merge stage can hold them (4 x nlists x k keys of LDS for a limb's two planes):
+    // the band kernel then ends without a workgroup barrier and without ranking its waves' lists against each other
+    // (3.4 us per workgroup at bs8 640x640, all of it exposed behind the last band); OG_K1_WAVE_LISTS=0: one list per band.
+    static const int wave_lists = env_int("OG_K1_WAVE_LISTS", 1);
+    p->wl = (wave_lists && p->nwaves > 1 && (size_t)4 * p->nbands * p->nwaves * k * sizeof(uint64_t) <= 40 * 1024) ? p->nwaves : 1;
+    p->nlists = p->nbands * p->wl;
+    // subset depth for the merge's lower bound: nlists * t_sub >= k whenever possible
+    p->t_sub = min(k, max(2, (k + p->nlists - 1) / p->nlists + 1));
     // [magic | histograms | band keys | band counts]; the magic word sits at offset 0 for every
     // shape and encodes the shape, so a call with another geometry (or in plain top-k mode)
     // invalidates whatever histogram state an earlier geometry left behind
     p->magic_off = 0;
     p->hist_off = 256;
     p->keys_off = p->hist_off + og_align_up((size_t)planes * kHistBins * sizeof(int), 256);
-    p->cnt_off = p->keys_off + og_align_up((size_t)planes * p->nbands * k * sizeof(uint64_t), 256);
-    p->bytes = p->cnt_off + og_align_up((size_t)planes * p->nbands * sizeof(int), 256);
+    p->cnt_off = p->keys_off + og_align_up((size_t)planes * p->nlists * k * sizeof(uint64_t), 256);
+    p->bytes = p->cnt_off + og_align_up((size_t)planes * p->nlists * sizeof(int), 256);
     p->magic = kWsMagic ^ ((uint64_t)planes * 0x9E3779B97F4A7C15ull + (uint64_t)H * 0x100000001B3ull +
                            (uint64_t)W * 0xC2B2AE3D27D4EB4Full + (uint64_t)k * 0x165667B19E3779F9ull);
     return true;
@@ -934,6 +983,9 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
         OG_REQUIRE(p.nwaves < kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide", name, W);
         p.panel_strips = (w4 + p.nwaves - 1) / p.nwaves;
         OG_REQUIRE(p.rows % 4 == 0 || p.nbands == 1, OG_EUNSUPPORTED, "%s: rows per band must be a multiple of 4", name);
+        p.wl = 1;   // (its wave count is not the plan's, which sized the workspace: one list per band)
+        p.nlists = p.nbands;
+        p.t_sub = min(k, max(2, (k + p.nlists - 1) / p.nlists + 1));
     }
     OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
@@ -960,10 +1012,11 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
             TailArgs tl;
             tl.tickets = pair->tickets;
             tl.out_scores = out_scores; tl.out_inds = out_inds;
-            tl.ca = pair->a; tl.nd = pair->nd; tl.t_sub = p.t_sub; tl.planes = (int)planes;
+            tl.ca = pair->a; tl.nd = pair->nd; tl.planes = (int)planes;
+            tl.t_sub = min(k, max(2, (k + p.nbands - 1) / p.nbands + 1));   // one list per band in this form
             hipLaunchKernelGGL((band_topk_kernel<4, true, kPrefetch, kBandAbl, false, true>), dim3(padded), block, lds > tlds ? lds : tlds,
                                stream, in, keys, cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips,
-                               (int)total, padded, helper, tl);
+                               (int)total, padded, helper, 1, tl);
             OG_LAUNCH_CHECK(name);
             return 1;   // paired
         }
@@ -971,20 +1024,20 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     if (FUSED)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
                            cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded,
-                           helper, no_tail);
+                           helper, p.wl, no_tail);
     else if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys, cnts,
                            hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
-                           no_tail);
+                           p.wl, no_tail);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
                            hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
-                           no_tail);
+                           p.wl, no_tail);
     OG_LAUNCH_CHECK(name);
     // dynamic LDS the merge kernels may ask for without raising the 64 KiB default: their static __shared__ words (bounds,
     // counters: 24 B) come on top
     constexpr size_t kDynLdsLimit = 64 * 1024 - 256;
-    const size_t mlds = (size_t)2 * p.nbands * k * sizeof(uint64_t);
+    const size_t mlds = (size_t)2 * p.nlists * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= kDynLdsLimit, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
     if constexpr (NMS_MODE && !FUSED) {
         const size_t plds = 2 * mlds + (size_t)((k + 3) & ~3) * 32;
@@ -992,13 +1045,13 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
             const int NL = pair->N * pair->a.L;
             auto kern = pair->nd == 2 ? merge_collect_kernel<2> : merge_collect_kernel<4>;
             hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, cnts, hist, magic,
-                               p.magic, in, (int)planes, p.nbands, p.t_sub, out_scores, out_inds, pair->a, NL);
+                               p.magic, in, (int)planes, p.nbands, p.nlists, p.t_sub, out_scores, out_inds, pair->a, NL);
             OG_LAUNCH_CHECK(name);
             return 1;   // paired
         }
     }
     hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
-                       magic, p.magic, in, H, W, k, p.nbands, p.t_sub, out_scores, out_inds);
+                       magic, p.magic, in, H, W, k, p.nbands, p.nlists, p.t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -1162,4 +1215,5 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
 
 #ifdef OG_K1_STAMPS
 OG_API void og_k1_debug_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1_stamps), sizeof(g_k1_stamps)); }
+OG_API void og_k1_band_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_band_stamps), sizeof(g_band_stamps)); }
 #endif
