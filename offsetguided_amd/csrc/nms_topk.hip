@@ -46,9 +46,14 @@ __device__ long long g_k1_stamps[1024 * 16];
 #define OG_COLLECT_STAMP(i, dep) do { if (threadIdx.x == 0 && g_k1_stamps[blockIdx.x * 16 + (i)] == 0 && (dep) == (dep)) g_k1_stamps[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
 __device__ long long g_band_stamps[2048 * 8];   // band_topk_kernel / merge_collect_kernel: [workgroup][time point]
 #define BAND_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_band_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+__device__ long long g_wave_stamps[2048 * 16];   // band_topk_kernel: [workgroup][wave 0..3][stream done, end, pushes, compactions]
+#define WAVE_STAMP(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048 && (threadIdx.x >> 6) < 4) g_wave_stamps[blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (i)] = (long long)(v); } while (0)
+#define BAND_STAMP_MAX(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) atomicMax((unsigned long long *)&g_band_stamps[blockIdx.x * 8 + (i)], (unsigned long long)wall_clock64()); } while (0)
 #define MERGE_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 900) g_band_stamps[(1100 + blockIdx.x) * 8 + (i)] = (long long)wall_clock64(); } while (0)
 #else
 #define BAND_STAMP(i) do { } while (0)
+#define BAND_STAMP_MAX(i) do { } while (0)
+#define WAVE_STAMP(i, v) do { } while (0)
 #define MERGE_STAMP(i) do { } while (0)
 #endif
 #include "collect_body.h"
@@ -60,6 +65,9 @@ namespace {
 #define OG_K1_LOAD_AUX 0  // default cache policy.  nt (2) reads an HBM-cold batch 2 us faster (56 vs 58 us for the two launches), but in the
                           // decode pipeline the batch has just been written by K1a and sits in the Infinity Cache: there nt loads cost
                           // 60 us (66 behind the backbone) against 57 -- tools/k1_bench.py, every policy (sc0, sc1, nt, combinations)
+#endif
+#ifndef OG_K1_TOUCH
+#define OG_K1_TOUCH 1   // merge stage requests the offset taps of every from-candidate that passes its filter (tools/build_variants.sh A/B)
 #endif
 #ifndef OG_K1_BAND_PF
 #define OG_K1_BAND_PF 3
@@ -261,7 +269,38 @@ __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, i
     }
 }
 
-__device__ __forceinline__ TileGeom make_geom(int H, int W, int rows, int band, int panel_strips, int vec)
+// Work items of the band kernel: plane p is cut into b_lo or b_lo + 1 bands (n_hi of the planes, spread evenly, take the extra
+// one), so that the launch has a chosen number of workgroups -- a multiple of the CU count: at bs8 640x640 1 024 instead of
+// 136 x 8 = 1 088, whose 64 extra workgroups put a fifth one on every fourth CU and set the end of the stream (stamps:
+// 36 us against 32.5 us for the others).  Item index = start(p) + band; band boundaries are multiples of 4 rows.
+struct BandMap {
+    int planes, b_lo, n_hi;
+};
+// (32-bit arithmetic: make_plan only builds maps whose products fit -- 64-bit divisions cost the band kernel 1 us of set-up)
+__host__ __device__ __forceinline__ int bm_start(const BandMap &m, int p) { return p * m.b_lo + (int)(((unsigned)p * (unsigned)m.n_hi) / (unsigned)m.planes); }
+__host__ __device__ __forceinline__ int bm_row(int b, int nb, int H)
+{
+    if (b >= nb) return H;
+    if (H < (1 << 20)) return (int)((((unsigned)b * (unsigned)H) / (unsigned)nb) & ~3u);   // (at most 64 bands)
+    return (int)((((long)b * H) / nb) & ~3l);
+}
+__device__ __forceinline__ void bm_locate(const BandMap &m, int total, int wid, int &plane, int &band, int &nb)
+{
+    if (m.n_hi == 0) {   // equal band counts (any number of planes)
+        plane = wid / m.b_lo;
+        band = wid - plane * m.b_lo;
+        nb = m.b_lo;
+        return;
+    }
+    int p = (int)(((unsigned)wid * (unsigned)m.planes) / (unsigned)total);
+    while (p + 1 < m.planes && bm_start(m, p + 1) <= wid) ++p;
+    while (p > 0 && bm_start(m, p) > wid) --p;
+    plane = p;
+    band = wid - bm_start(m, p);
+    nb = bm_start(m, p + 1) - bm_start(m, p);
+}
+
+__device__ __forceinline__ TileGeom make_geom(int H, int W, int r0, int r1, int panel_strips, int vec)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int strips = (W + vec - 1) / vec;
@@ -271,8 +310,8 @@ __device__ __forceinline__ TileGeom make_geom(int H, int W, int rows, int band, 
     TileGeom g;
     g.plane_rows = H;
     g.plane_cols = W;
-    g.r0 = band * rows;
-    g.r1 = min(g.r0 + rows, H);
+    g.r0 = r0;
+    g.r1 = r1;
     g.col = s * vec;
     g.interior = lane >= 1 && lane <= s_cnt;
     const bool loads = lane <= s_cnt + 1 && s >= 0 && s < strips;
@@ -291,7 +330,7 @@ nms_map_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
     const int plane = wid / nbands, band = wid % nbands;
-    const TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
+    const TileGeom g = make_geom(H, W, band * rows, min(band * rows + rows, H), panel_strips, VEC);
     const float *src = in + (size_t)plane * H * W;
     float *dst = out + (size_t)plane * H * W;
     walk_panel<VEC, kPrefetch>(src, g, [&](int row, const Px<VEC> &v, const Px<VEC> &ha, const Px<VEC> &hb, const Px<VEC> &hc) {
@@ -326,6 +365,7 @@ struct WaveSeg {
     float lane_tau_f;
     int *hist;            // plane histogram (global) or nullptr
     int npush = 0;        // debug statistics (OG_K1_DEBUG)
+    int ncompact = 0;
 
     __device__ __forceinline__ void set_tau(float t)
     {
@@ -339,6 +379,25 @@ struct WaveSeg {
     __device__ __forceinline__ void compact(int k)
     {
         const int lane = threadIdx.x & 63;
+        ++ncompact;
+        // 1) One ballot pass drops the keys below TODAY's admission threshold: it is a lower bound of the plane's k-th best
+        //    that has risen since they were admitted (compactions, the helper's plane-wide bound), so they cannot be among
+        //    the k best.  Ranking by counting costs cnt^2 / 64 64-bit compares per lane -- 1.7 us for the last compaction of
+        //    a wave at bs8 640x640, all of it behind the stream -- and is left with the few keys that matter.
+        const uint32_t tau_hi = (uint32_t)(og_make_key(tau_f, 0u) >> 32);
+        int kept = 0;
+        for (int base = 0; base < cnt; base += 64) {
+            const int i = base + lane;
+            const uint64_t key = i < cnt ? cur[i] : 0ull;
+            const bool keep = i < cnt && (uint32_t)(key >> 32) >= tau_hi;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) alt[kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = key;
+            kept += __builtin_popcountll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        { uint64_t *t = cur; cur = alt; alt = t; }
+        cnt = kept;
+        // 2) rank the survivors
         for (int i = lane; i < cnt; i += 64) {
             const uint64_t mine = cur[i];
             const int rank = og_count_greater(cur, cnt, mine);  // LDS broadcast reads
@@ -381,10 +440,14 @@ struct WaveSeg {
 // zero-padded by their writers (a key is never zero).  `all` / `flt`: n_all = nlists * k keys each, in LDS;
 // `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
 // SC1: the band lists were written in THIS launch by other workgroups (sc1 stores): read them with sc1 loads.
-template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit>
+struct NoPass {
+    __device__ __forceinline__ void operator()(uint64_t) const {}
+};
+template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit, class Pass = NoPass>
 __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uint64_t *all,
                                             uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
-                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit)
+                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit,
+                                            Pass &&on_pass = NoPass())
 {
     const int n_all = nlists * k, lane = tid & 63;
     // All of a thread's keys are requested before the first one is used (one memory round trip, not one per key), and
@@ -405,6 +468,7 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
     }
     if (tid == 0) { *s_bound = 0ull; *s_nf = 0; }
     __syncthreads();
+    MERGE_STAMP(3);
     // A) k-th largest of the subset {first t_sub keys of each list}: a lower bound of the plane's k-th best
     const int n_sub = nlists * t_sub;
     for (int i = tid; i < n_sub; i += nthr) {
@@ -412,14 +476,22 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
         if (mine != 0ull && og_count_greater(all, n_sub, mine) == k - 1) *s_bound = mine;
     }
     __syncthreads();
+    MERGE_STAMP(4);
     const uint64_t bound = *s_bound;
     // B) keys >= bound (order does not matter: ranks are recomputed)
     for (int i = tid; i < n_all; i += nthr) {
         const uint64_t key = all[i];
-        if (key != 0ull && key >= bound) flt[atomicAdd(s_nf, 1)] = key;
+        if (key != 0ull && key >= bound) {
+            flt[atomicAdd(s_nf, 1)] = key;
+            on_pass(key);   // (a superset of the k best, known one ranking step before them)
+        }
     }
     __syncthreads();
+    MERGE_STAMP(5);
     const int nf = *s_nf;
+#ifdef OG_K1_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 900) g_band_stamps[(1100 + blockIdx.x) * 8 + 7] = nf;
+#endif
     // C) rank and emit
     for (int i = tid; i < nf; i += nthr) {
         const uint64_t mine = flt[i];
@@ -471,9 +543,9 @@ struct TailArgs {
 template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false, bool TAIL = false>
 // (amdgpu_waves_per_eu: <= 96 VGPRs -- at bs8 640x640 all 1 088 workgroups must be resident together, 5 per CU)
 __global__ void __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(5)))
-band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys, int *__restrict__ band_cnt,
+band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                  int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
-                 int H, int W, int k, int cap, int rows, int nbands, int panel_strips, int total, int padded, int helper,
+                 int H, int W, int k, int cap, BandMap bm, int max_bands, int panel_strips, int total, int padded, int helper,
                  int wl, TailArgs tl)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
@@ -487,13 +559,10 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     BAND_STAMP(0);
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
-#ifdef OG_K1_REVERSE_PLANES   // A/B: read first what K1a wrote last; measured no gain
-    const int plane = total / nbands - 1 - wid / nbands, band = wid % nbands;
-#else
-    const int plane = wid / nbands, band = wid % nbands;
-#endif
+    int plane, band, nbands;   // nbands: bands of THIS plane
+    bm_locate(bm, total, wid, plane, band, nbands);
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    TileGeom g = make_geom(H, W, rows, band, panel_strips, VEC);
+    TileGeom g = make_geom(H, W, bm_row(band, nbands, H), bm_row(band + 1, nbands, H), panel_strips, VEC);
     int q_lane = 0;
     if constexpr (FUSED) {  // lanes = source columns: 58 interior + 3 halo lanes each side
         const int lane = threadIdx.x & 63, w4 = W >> 2;
@@ -527,7 +596,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     const int hmode = helper;   // bit 0: helper wave present; bit 3: debug statistics (tools/)
     helper &= 1;
     const int nstream = (blockDim.x >> 6) - helper;   // streaming waves
-    int *gslot = (NMS_MODE && helper && *ws_magic == magic) ? hist_all + (size_t)plane * nbands : nullptr;
+    int *gslot = (NMS_MODE && helper && *ws_magic == magic) ? hist_all + (size_t)plane * max_bands : nullptr;
     seg.hist = gslot ? s_hist : nullptr;
     int *s_done = s_tau_p + 1;
     if (gslot) {
@@ -604,6 +673,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             // the row prefetch queue (vmcnt(0)) on EVERY iteration of the streaming waves
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
+        BAND_STAMP_MAX(6);   // helper wave leaves its loop
     }
     // A streaming wave reports itself done a few rows BEFORE its last one: the helper (whose bound could no longer save
     // anything) then leaves ahead of the streaming waves instead of up to one polling period behind them.
@@ -666,11 +736,12 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     }
     if (gslot && lane_id == 0 && wave < nstream && !reported) atomicAdd(s_done, 1);
     if ((hmode & 8) && hist_all && lane_id == 0 && wave < nstream) {  // debug: pushes / final threshold / waves, kept in the unused tail of the slot region
-        int *dbg = hist_all + (size_t)(total / nbands) * kHistBins - 16;
+        int *dbg = hist_all + (size_t)bm.planes * kHistBins - 16;
         atomicAdd(dbg + 0, seg.npush); atomicMax(dbg + 1, seg.tau_bits); atomicAdd(dbg + 2, 1); atomicAdd(dbg + 3, seg.tau_bits > 1 ? 1 : 0);
     }
 
     BAND_STAMP(2);
+    WAVE_STAMP(0, wall_clock64());
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
     BAND_STAMP(3);
@@ -678,18 +749,22 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         // one list per streaming wave (wl = streaming waves per band): no workgroup barrier, no cross-wave ranking here --
         // the merge launch ranks the plane's nbands * wl sorted lists anyway.  The helper wave has no list.
         if (wave < nstream) {
-            const size_t li = ((size_t)plane * nbands + band) * wl + wave;
+            const size_t li = (size_t)wid * wl + wave;
             const int c = min(seg.cnt, k);
             for (int i = lane_id; i < k; i += 64) band_keys[li * k + i] = i < c ? seg.cur[i] : 0ull;   // zero-padded
         }
         BAND_STAMP(4);
+        BAND_STAMP_MAX(5);   // last wave of the workgroup done
+        WAVE_STAMP(1, wall_clock64());
+        WAVE_STAMP(2, seg.npush);
+        WAVE_STAMP(3, seg.ncompact);
         return;
     }
     if ((threadIdx.x & 63) == 0) { s_cnt[wave] = min(seg.cnt, k); s_slot[wave] = (int)((seg.cur - smem) / cap); }
     __syncthreads();
     int total_keys = 0;
     for (int w = 0; w < nwaves; ++w) total_keys += s_cnt[w];
-    uint64_t *out = band_keys + ((size_t)plane * nbands + band) * k;
+    uint64_t *out = band_keys + (size_t)wid * k;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t okr = __builtin_amdgcn_make_buffer_rsrc(out, 0, k * 8, 0x00020000);
     for (int t = threadIdx.x; t < total_keys; t += blockDim.x) {
@@ -742,12 +817,12 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         int *s_todo = s_nf + 1;                   // [0] count, [1..] limb types this workgroup pairs
         __syncthreads();                          // s_flag read by everyone before the region is reused
         if (hist_all)   // the plane's slot table is no longer read: leave it clean for the next call
-            for (int i = tid; i < nbands; i += nthr) hist_all[(size_t)plane * nbands + i] = 0;
+            for (int i = tid; i < max_bands; i += nthr) hist_all[(size_t)plane * max_bands + i] = 0;
         float *os = tl.out_scores + (size_t)plane * k;
         int64_t *oi = tl.out_inds + (size_t)plane * k;
         const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(os, 0, k * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(oi, 0, k * 8, 0x00020000);
-        merge_plane<true, false, true>(band_keys + (size_t)plane * n_all, all, flt, s_bound,
+        merge_plane<true, false, true>(band_keys + (size_t)(wid - band) * k, all, flt, s_bound,
                                        s_nf, tid, nthr, in + (size_t)plane * H * W, H, W, k, nbands, tl.t_sub,
                                        [&](int rank, float v, long idx) {
                                            u32x2 w;
@@ -783,13 +858,13 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         __syncthreads();
         const int ntodo = s_todo[0];
         // one wave per limb type: both (k) lists by sc1 loads into the wave's LDS scratch, then collect_body.h
-        float *wl = reinterpret_cast<float *>(smem) + ((4 * n_all + 2 + 2 + L + 1 + 3) & ~3) + (size_t)wave * 8 * Kp;   // 16-byte aligned
+        float *wsc = reinterpret_cast<float *>(smem) + ((4 * n_all + 2 + 2 + L + 1 + 3) & ~3) + (size_t)wave * 8 * Kp;   // 16-byte aligned
         for (int t = wave; t < ntodo; t += nwaves) {
             const int l = s_todo[1 + t];
             const int pf = n * C + tl.ca.jf[l], pt = n * C + tl.ca.jt[l];
-            float *lsf = wl, *lst = wl + Kp;
-            int *lif = reinterpret_cast<int *>(wl + 2 * Kp), *lit = lif + Kp;
-            float *sm = wl + 4 * Kp;
+            float *lsf = wsc, *lst = wsc + Kp;
+            int *lif = reinterpret_cast<int *>(wsc + 2 * Kp), *lit = lif + Kp;
+            float *sm = wsc + 4 * Kp;
             const __amdgpu_buffer_rsrc_t s_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_scores, 0, tl.planes * k * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t i_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_inds, 0, tl.planes * k * 8, 0x00020000);
             for (int i = lane; i < k; i += 64) {
@@ -827,22 +902,21 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
 // ---------------------------------------------------------------------------------------
 template <bool NMS_MODE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
-merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt,
-                   int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
-                   const float *__restrict__ in, int H, int W, int k, int nbands, int nlists, int t_sub,
+merge_bands_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic,
+                   uint64_t magic, const float *__restrict__ in, int H, int W, int k, BandMap bm, int max_bands, int wl, int t_sub,
                    float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const int plane = blockIdx.x, tid = threadIdx.x;
-    const int n_all = nlists * k;
+    const int first = bm_start(bm, plane), nlists = (bm_start(bm, plane + 1) - first) * wl;
     __shared__ uint64_t s_bound;
     __shared__ int s_nf;
     float *os = out_scores + (size_t)plane * k;
     int64_t *oi = out_inds + (size_t)plane * k;
     if (hist_all)  // leave the workspace clean (zero slots + this geometry's magic) for the next call
-        for (int i = tid; i < nbands; i += blockDim.x) hist_all[(size_t)blockIdx.x * nbands + i] = 0;
+        for (int i = tid; i < max_bands; i += blockDim.x) hist_all[(size_t)blockIdx.x * max_bands + i] = 0;
     if (blockIdx.x == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
-    merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)plane * n_all, lds64, lds64 + n_all,
+    merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)first * wl * k, lds64, lds64 + (size_t)max_bands * wl * k,
                                  &s_bound, &s_nf, tid, 256,
                                  in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W), H, W, k, nlists,
                                  t_sub, [&](int rank, float v, long idx) { os[rank] = v; oi[rank] = (int64_t)idx; });
@@ -855,15 +929,15 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict
 // a launch, a launch gap and a round trip of the lists through memory.
 template <int ND>
 __global__ void __launch_bounds__(512)
-merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restrict__ band_cnt, int *__restrict__ hist_all,
-                     uint64_t *__restrict__ ws_magic, uint64_t magic, const float *__restrict__ in, int planes, int nbands,
-                     int nlists, int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
+merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ hist_all,
+                     uint64_t *__restrict__ ws_magic, uint64_t magic, const float *__restrict__ in, BandMap bm, int max_bands,
+                     int wl, int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint64_t s_bound[2];
     __shared__ int s_nf[2];
     MERGE_STAMP(0);
-    const int k = a.K, H = a.H, W = a.W, n_all = nlists * k, Kp = (k + 3) & ~3;
+    const int planes = bm.planes, k = a.K, H = a.H, W = a.W, n_all = max_bands * wl * k, Kp = (k + 3) & ~3;   // n_all: LDS carve-up
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
     uint64_t *all = lds64 + (size_t)half * 2 * n_all, *flt = all + n_all;
     float *ls = reinterpret_cast<float *>(lds64 + 4 * (size_t)n_all);   // [2][Kp] scores | [2][Kp] indices | pairing scratch
@@ -881,23 +955,33 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, const int *__restri
         live = plane < planes;
         plane = live ? plane : planes - 1;   // the odd plane out: merged twice, written once
         if (live && hist_all)
-            for (int i = tid; i < nbands; i += 256) hist_all[(size_t)plane * nbands + i] = 0;
+            for (int i = tid; i < max_bands; i += 256) hist_all[(size_t)plane * max_bands + i] = 0;
         if (plane == 0 && tid == 0) *ws_magic = hist_all ? magic : 0ull;
     }
     float *os = limb ? ls + half * Kp : out_scores + (size_t)plane * k;
     int *oi32 = li + half * Kp;
+    float touched = 0.f;
     int64_t *oi64 = out_inds + (size_t)plane * k;
-    merge_plane<true, false>(band_keys + (size_t)plane * n_all, all, flt, &s_bound[half],
+    const int first = bm_start(bm, plane), nlists = (bm_start(bm, plane + 1) - first) * wl;
+    merge_plane<true, false>(band_keys + (size_t)first * wl * k, all, flt, &s_bound[half],
                              &s_nf[half], tid, 256, in + (size_t)plane * H * W, H, W, k, nlists, t_sub,
                              [&](int rank, float v, long idx) {
                                  if (limb) { os[rank] = v; oi32[rank] = (int)idx; }
                                  else if (live) { os[rank] = v; oi64[rank] = (int64_t)idx; }
+                             },
+                             [&](uint64_t key) {   // from-candidates of a limb: their offset taps are on the way before they are ranked
+#if OG_K1_TOUCH
+                                 if (limb && half == 0) touched += og_collect::touch_offsets<ND>(a, n, l, (int)og_key_index(key));
+#else
+                                 (void)key;
+#endif
                              });
     if (!limb) return;
     __syncthreads();
     MERGE_STAMP(1);
     if (threadIdx.x < 64) og_collect::limb_rows<ND, int>(a, n, l, threadIdx.x, ls, li, ls + Kp, li + Kp, sm);
     MERGE_STAMP(2);
+    if (touched == 1.0e38f) sm[threadIdx.x & 1] = touched;   // never true for sums of finite taps worth using: keeps the loads alive
 }
 
 // dynamic LDS the tail of band_topk_kernel<..., TAIL> needs (see its carve-up), for a workgroup of `waves` waves
@@ -908,9 +992,12 @@ size_t band_tail_lds_bytes(int nbands, int k, int L, int waves)
 }
 
 struct Plan {
-    int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;
-    int wl, nlists;   // sorted k-lists a band hands to the merge: one (cross-wave ranking in the band kernel) or one per streaming wave
-    size_t keys_off, cnt_off, hist_off, magic_off, bytes;
+    int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;   // rows / nbands: equal bands (og_hmp_nms_f32)
+    BandMap bm;       // the band kernel's work items
+    int max_bands;    // most bands a plane has (slot table stride, LDS of the merge stage)
+    int total;        // work items = workgroups of the band kernel
+    int wl;           // sorted k-lists a band hands to the merge: one (cross-wave ranking in the band kernel) or one per streaming wave
+    size_t keys_off, hist_off, magic_off, bytes;
     uint64_t magic;
 };
 
@@ -919,6 +1006,8 @@ int env_int(const char *name, int dflt)
     const char *s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
 }
+
+int device_cu_count();
 
 bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
 {
@@ -932,26 +1021,39 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     rows = min(rows, H);
     p->rows = rows;
     p->nbands = (H + rows - 1) / rows;
+    // Work items: the multiple of the CU count nearest to planes x nbands, when that keeps the bands within a quarter of the
+    // tuned height (OG_K1_BAND_WGS_PER_CU: 0 = equal bands of OG_NMS_ROWS rows, n > 0 = n workgroups per CU)
+    static const int per_cu_env = env_int("OG_K1_BAND_WGS_PER_CU", -1);
+    p->bm = BandMap{(int)planes, p->nbands, 0};
+    if (per_cu_env != 0 && planes < (1l << 12) && H < (1 << 20)) {   // (planes x work items and bands x H stay below 2^32)
+        const long cus = device_cu_count(), uniform = planes * p->nbands;
+        const long per_cu = per_cu_env > 0 ? per_cu_env : (uniform + cus / 2) / cus;
+        const long T = per_cu * cus;
+        if (T >= planes && T < (1l << 19) && T / planes + 1 <= 64 && H / (T / planes + 1) >= 16 && 4 * labs(T - uniform) <= uniform)
+            p->bm = BandMap{(int)planes, (int)(T / planes), (int)(T % planes)};
+    }
+    p->max_bands = p->bm.b_lo + (p->bm.n_hi > 0 ? 1 : 0);
+    p->total = bm_start(p->bm, (int)planes);
     p->cap = (2 * k + 64 + 63) / 64 * 64;
     if ((size_t)p->nwaves * 2 * p->cap * sizeof(uint64_t) > 60 * 1024) return false;
-    // One list per streaming wave when the merge stage can hold them (4 x nlists x k keys of LDS for a limb's two planes):
+    // One list per streaming wave when the merge stage can hold them (4 x lists x k keys of LDS for a limb's two planes):
     // the band kernel then ends without a workgroup barrier and without ranking its waves' lists against each other
     // (3.4 us per workgroup at bs8 640x640, all of it exposed behind the last band); OG_K1_WAVE_LISTS=0: one list per band.
     static const int wave_lists = env_int("OG_K1_WAVE_LISTS", 1);
-    p->wl = (wave_lists && p->nwaves > 1 && (size_t)4 * p->nbands * p->nwaves * k * sizeof(uint64_t) <= 40 * 1024) ? p->nwaves : 1;
-    p->nlists = p->nbands * p->wl;
-    // subset depth for the merge's lower bound: nlists * t_sub >= k whenever possible
-    p->t_sub = min(k, max(2, (k + p->nlists - 1) / p->nlists + 1));
-    // [magic | histograms | band keys | band counts]; the magic word sits at offset 0 for every
-    // shape and encodes the shape, so a call with another geometry (or in plain top-k mode)
-    // invalidates whatever histogram state an earlier geometry left behind
+    p->wl = (wave_lists && p->nwaves > 1 && (size_t)4 * p->max_bands * p->nwaves * k * sizeof(uint64_t) <= 40 * 1024) ? p->nwaves : 1;
+    // subset depth for the merge's lower bound: lists * t_sub >= k whenever possible
+    const int min_lists = p->bm.b_lo * p->wl;
+    p->t_sub = min(k, max(2, (k + min_lists - 1) / min_lists + 1));
+    // [magic | slot tables | band keys]; the magic word sits at offset 0 for every shape and encodes the shape and the
+    // work-item map, so a call with another geometry (or in plain top-k mode) invalidates whatever slot-table state an
+    // earlier geometry left behind
     p->magic_off = 0;
     p->hist_off = 256;
     p->keys_off = p->hist_off + og_align_up((size_t)planes * kHistBins * sizeof(int), 256);
-    p->cnt_off = p->keys_off + og_align_up((size_t)planes * p->nlists * k * sizeof(uint64_t), 256);
-    p->bytes = p->cnt_off + og_align_up((size_t)planes * p->nlists * sizeof(int), 256);
+    p->bytes = p->keys_off + og_align_up((size_t)p->total * p->wl * k * sizeof(uint64_t), 256);
     p->magic = kWsMagic ^ ((uint64_t)planes * 0x9E3779B97F4A7C15ull + (uint64_t)H * 0x100000001B3ull +
-                           (uint64_t)W * 0xC2B2AE3D27D4EB4Full + (uint64_t)k * 0x165667B19E3779F9ull);
+                           (uint64_t)W * 0xC2B2AE3D27D4EB4Full + (uint64_t)k * 0x165667B19E3779F9ull +
+                           (uint64_t)p->total * 0x27D4EB2F165667C5ull);
     return true;
 }
 
@@ -977,24 +1079,22 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     Plan p;
     OG_REQUIRE(make_plan(planes, H, W, k, (uintptr_t)in % 16 == 0, &p), OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d",
                name, W, k);
-    if (FUSED) {  // lanes are source columns (58 interior per wave); bands must start on a source row
+    int wl = p.wl, t_sub = p.t_sub;
+    if (FUSED) {  // lanes are source columns (58 interior per wave); bands start on a source row (bm_row: multiples of 4)
         const int w4 = W / 4;
         p.nwaves = (w4 + 57) / 58;
         OG_REQUIRE(p.nwaves < kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide", name, W);
         p.panel_strips = (w4 + p.nwaves - 1) / p.nwaves;
-        OG_REQUIRE(p.rows % 4 == 0 || p.nbands == 1, OG_EUNSUPPORTED, "%s: rows per band must be a multiple of 4", name);
-        p.wl = 1;   // (its wave count is not the plan's, which sized the workspace: one list per band)
-        p.nlists = p.nbands;
-        p.t_sub = min(k, max(2, (k + p.nlists - 1) / p.nlists + 1));
+        wl = 1;   // (its wave count is not the plan's, which sized the workspace: one list per band)
+        t_sub = min(k, max(2, (k + p.bm.b_lo - 1) / p.bm.b_lo + 1));
     }
     OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
     uint64_t *keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
-    int *cnts = reinterpret_cast<int *>((char *)workspace + p.cnt_off);
-    int *hist = (NMS_MODE && p.nbands <= 64) ? reinterpret_cast<int *>((char *)workspace + p.hist_off) : nullptr;
+    int *hist = (NMS_MODE && p.max_bands <= 64) ? reinterpret_cast<int *>((char *)workspace + p.hist_off) : nullptr;
     uint64_t *magic = reinterpret_cast<uint64_t *>((char *)workspace + p.magic_off);
 
-    const long total = planes * p.nbands;
+    const long total = p.total;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
     const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
@@ -1005,7 +1105,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
         // og_generate_limbs_f32 with OG_LIMBS_TAIL_IN_BAND: merge + pairing inside the band launch, by last arrivers
         const int tail_in_band = pair ? pair->tail_in_band : 0;
         const int waves = p.nwaves + (helper & 1);
-        const size_t tlds = pair ? band_tail_lds_bytes(p.nbands, k, pair->a.L, waves) : 0;
+        const size_t tlds = pair ? band_tail_lds_bytes(p.max_bands, k, pair->a.L, waves) : 0;
         const size_t n_tickets = (size_t)planes + (size_t)pair_N(pair) * pair_L(pair) + 1;
         if (pair && pair->tickets && tail_in_band && p.vec == 4 && tlds <= 64 * 1024 && n_tickets * sizeof(int) <= pair->ticket_bytes &&
             (size_t)planes * k < (1u << 27)) {
@@ -1013,9 +1113,9 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
             tl.tickets = pair->tickets;
             tl.out_scores = out_scores; tl.out_inds = out_inds;
             tl.ca = pair->a; tl.nd = pair->nd; tl.planes = (int)planes;
-            tl.t_sub = min(k, max(2, (k + p.nbands - 1) / p.nbands + 1));   // one list per band in this form
+            tl.t_sub = min(k, max(2, (k + p.bm.b_lo - 1) / p.bm.b_lo + 1));   // one list per band in this form
             hipLaunchKernelGGL((band_topk_kernel<4, true, kPrefetch, kBandAbl, false, true>), dim3(padded), block, lds > tlds ? lds : tlds,
-                               stream, in, keys, cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips,
+                               stream, in, keys, hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips,
                                (int)total, padded, helper, 1, tl);
             OG_LAUNCH_CHECK(name);
             return 1;   // paired
@@ -1023,35 +1123,35 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     }
     if (FUSED)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
-                           cnts, hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded,
-                           helper, p.wl, no_tail);
+                           hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded,
+                           helper, wl, no_tail);
     else if (p.vec == 4)
-        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
-                           p.wl, no_tail);
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys,
+                           hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
+                           wl, no_tail);
     else
-        hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys, cnts,
-                           hist, magic, p.magic, H, W, k, p.cap, p.rows, p.nbands, p.panel_strips, (int)total, padded, helper,
-                           p.wl, no_tail);
+        hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys,
+                           hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
+                           wl, no_tail);
     OG_LAUNCH_CHECK(name);
     // dynamic LDS the merge kernels may ask for without raising the 64 KiB default: their static __shared__ words (bounds,
     // counters: 24 B) come on top
     constexpr size_t kDynLdsLimit = 64 * 1024 - 256;
-    const size_t mlds = (size_t)2 * p.nlists * k * sizeof(uint64_t);
+    const size_t mlds = (size_t)2 * p.max_bands * wl * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= kDynLdsLimit, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
     if constexpr (NMS_MODE && !FUSED) {
         const size_t plds = 2 * mlds + (size_t)((k + 3) & ~3) * 32;
         if (pair && plds <= kDynLdsLimit) {
             const int NL = pair->N * pair->a.L;
             auto kern = pair->nd == 2 ? merge_collect_kernel<2> : merge_collect_kernel<4>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, cnts, hist, magic,
-                               p.magic, in, (int)planes, p.nbands, p.nlists, p.t_sub, out_scores, out_inds, pair->a, NL);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, hist, magic,
+                               p.magic, in, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds, pair->a, NL);
             OG_LAUNCH_CHECK(name);
             return 1;   // paired
         }
     }
-    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, cnts, hist,
-                       magic, p.magic, in, H, W, k, p.nbands, p.nlists, p.t_sub, out_scores, out_inds);
+    hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, hist,
+                       magic, p.magic, in, H, W, k, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -1215,5 +1315,6 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
 
 #ifdef OG_K1_STAMPS
 OG_API void og_k1_debug_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1_stamps), sizeof(g_k1_stamps)); }
+OG_API void og_k1_wave_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps)); }
 OG_API void og_k1_band_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_band_stamps), sizeof(g_band_stamps)); }
 #endif

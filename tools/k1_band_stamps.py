@@ -15,6 +15,44 @@ from offsetguided_amd.config import coco_data as cd  # noqa: E402
 from tools.k1_bench import load  # noqa: E402
 
 
+def report(buf, n_limb_wgs, title, wbuf=None):
+    st = buf.reshape(2048, 8).astype(np.float64)
+    nb = int((st[:1100, 0] > 0).sum())   # workgroups of the band kernel
+    band, mrg = st[:nb], st[1100:1100 + n_limb_wgs]
+    t0 = band[:, 0].min()
+    b = (band[:, :5] - t0) / 100.0
+    m = (mrg[:, :3] - t0) / 100.0
+    mi = (mrg[:, 3:6] - t0) / 100.0   # inside merge_plane: keys in LDS, bound known, filtered
+    nf = mrg[:, 7]
+    q = lambda v: f'min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}'
+    print(title)
+    for j, nm in enumerate(['band entry', 'set-up done', 'stream done', 'compacted', 'list stored']):
+        print(f'   {nm:13s} {q(b[:, j])}')
+    allw, hlp = (band[:, 5] - t0) / 100.0, (band[:, 6] - t0) / 100.0
+    print(f'   all waves done {q(allw)};  helper left {q(hlp)};  last wave behind wave 0: {q(allw - b[:, 4])}')
+    if wbuf is not None:
+        wv = wbuf.reshape(2048, 4, 4)[:nb, :3].astype(np.float64)   # [wg][streaming wave][stream done, end, pushes, compactions]
+        wdone, wend = (wv[:, :, 0] - t0) / 100.0, (wv[:, :, 1] - t0) / 100.0
+        slow = np.argsort(wend.max(axis=1))[-6:]
+        for g_ in slow:
+            print(f'   late workgroup {g_}: set-up done {b[g_, 1]:.1f}; per wave stream done {np.round(wdone[g_], 1)}, end {np.round(wend[g_], 1)}, pushes {wv[g_, :, 2].astype(int)}, compactions {wv[g_, :, 3].astype(int)}')
+        sd = (wdone - b[:, 1:2]).ravel()
+        print(f'   per wave: stream time {q(sd)};  pushes {q(wv[:, :, 2].ravel())};  corr(pushes, stream time) = {np.corrcoef(wv[:, :, 2].ravel(), sd)[0, 1]:.2f};  end - stream done {q((wend - wdone).ravel())}')
+    dur, done, blk = b[:, 2] - b[:, 1], b[:, 2], np.arange(nb)
+    print('   stream duration by XCD (blockIdx % 8):', np.round([dur[blk % 8 == x].mean() for x in range(8)], 1), ' stream done:', np.round([done[blk % 8 == x].mean() for x in range(8)], 1), ' max:', np.round([done[blk % 8 == x].max() for x in range(8)], 1))
+    j = blk // 8   # dispatch order within the XCD = plane-major work item index (og_xcd_remap)
+    grp = nb // 8 // 16
+    print(f'   {nb} workgroups; by dispatch order (16 groups of {grp} per XCD): duration', np.round([dur[(j // grp) == pl].mean() for pl in range(16)], 1))
+    print('                                          done    ', np.round([done[(j // grp) == pl].mean() for pl in range(16)], 1))
+    print('   by position in a round of 32 (j % 32, groups of 4): duration', np.round([dur[(j % 32) // 4 == bd].mean() for bd in range(8)], 1), ' done', np.round([done[(j % 32) // 4 == bd].mean() for bd in range(8)], 1))
+    print(f'   corr(entry, duration) = {np.corrcoef(b[:, 0], dur)[0, 1]:.2f}')
+    print(f'   stream duration {q(b[:, 2] - b[:, 1])};  compaction {q(b[:, 3] - b[:, 2])};  merge+store {q(b[:, 4] - b[:, 3])}')
+    for j, nm in enumerate(['merge entry', 'planes merged', 'rows written']):
+        print(f'   {nm:13s} {q(m[:, j])}')
+    print(f'   merge: entry -> keys in LDS {q(mi[:, 0] - m[:, 0])};  -> bound {q(mi[:, 1] - mi[:, 0])};  -> filtered {q(mi[:, 2] - mi[:, 1])};  -> ranked + emitted {q(m[:, 1] - mi[:, 2])};  keys past the filter {q(nf)}')
+    print(f'   merge duration {q(m[:, 1] - m[:, 0])};  pairing {q(m[:, 2] - m[:, 1])};  gap last band -> first merge {m[:, 0].min() - b[:, 4].max():.2f}')
+
+
 def main():
     lib = load(sys.argv[1])
     lib.og_k1_band_stamps.argtypes = [C.c_void_p]
@@ -22,9 +60,15 @@ def main():
     _lib.load()
     sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     n, c, k, L, h, w = 8, 17, 32, 19, 640, 640
-    hm, off = synth.synth_batch(0, n, h, w)
-    lrs = [torch.from_numpy(hm).to(dev) * (1.0 - 0.01 * r) for r in range(3)]
-    t_off = torch.from_numpy(off).to(dev)
+    if '--bench-inputs' in sys.argv:
+        from tools.k1_bench import bench_inputs
+        bi = bench_inputs(dev, 3, n, h)
+        lrs = [x[0] for x in bi]
+        t_off = bi[0][1]
+    else:
+        hm, off = synth.synth_batch(0, n, h, w)
+        lrs = [torch.from_numpy(hm).to(dev) * (1.0 - 0.01 * r) for r in range(3)]
+        t_off = torch.from_numpy(off).to(dev)
     hrs = [torch.empty((n, c, h, w), device=dev) for _ in range(3)]
     for i in range(3):
         _lib.check(lib.og_upsample_bicubic4_f32(_lib.ptr(lrs[i]), n * c, h // 4, w // 4, _lib.ptr(hrs[i]), sp), lib)
@@ -34,7 +78,8 @@ def main():
     limbs = torch.empty((n, L, k, 13), device=dev)
     sc = torch.empty((n, c, k), device=dev)
     ix = torch.empty((n, c, k), dtype=torch.int64, device=dev)
-    nb = 1088
+    if len(sys.argv) > 2:
+        buf0 = np.zeros(2048 * 8, np.int64)
     for it in range(10):
         _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[it % 3]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
                                              _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc), _lib.ptr(ix),
@@ -44,19 +89,14 @@ def main():
         lib.og_k1_band_stamps(buf.ctypes.data)
         if it < 4:
             continue
-        st = buf.reshape(2048, 8).astype(np.float64)
-        band, mrg = st[:nb], st[1100:1100 + n * L]
-        t0 = band[:, 0].min()
-        b = (band[:, :5] - t0) / 100.0
-        m = (mrg[:, :3] - t0) / 100.0
-        q = lambda v: f'min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}'
-        print(f'launch {it}:')
-        for j, nm in enumerate(['band entry', 'set-up done', 'stream done', 'compacted', 'list stored']):
-            print(f'   {nm:13s} {q(b[:, j])}')
-        print(f'   stream duration {q(b[:, 2] - b[:, 1])};  compaction {q(b[:, 3] - b[:, 2])};  merge+store {q(b[:, 4] - b[:, 3])}')
-        for j, nm in enumerate(['merge entry', 'planes merged', 'rows written']):
-            print(f'   {nm:13s} {q(m[:, j])}')
-        print(f'   merge duration {q(m[:, 1] - m[:, 0])};  pairing {q(m[:, 2] - m[:, 1])};  gap last band -> first merge {m[:, 0].min() - b[:, 4].max():.2f}')
+        wbuf = np.zeros(2048 * 16, np.int64)
+        lib.og_k1_wave_stamps.argtypes = [C.c_void_p]
+        lib.og_k1_wave_stamps(wbuf.ctypes.data)
+        report(buf, n * L, f'launch {it}:', wbuf)
+        if os.environ.get('OG_K1_HELPER') == '9':   # debug statistics of the band kernel (helper bit 3), accumulated over the launches
+            off = 65536 + 256 + (n * c * 256 - 16) * 4
+            d = ws[off:off + 16].view(torch.int32).cpu().numpy()
+            print(f'   pushes so far {d[0]} over {d[2]} wave runs = {d[0] / max(d[2], 1):.1f} per wave; waves that ended above the start threshold {d[3]}')
         sys.stdout.flush()
 
 
