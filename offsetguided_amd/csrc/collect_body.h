@@ -57,35 +57,6 @@ struct Args {
     float *limbs;          // (N, L, K, 13)
 };
 
-// The memory lines limb_rows() will gather the guiding offset of from-candidate `id` from, requested ahead of time by
-// whoever knows the candidate first (the merge stage, for every key that passes its filter): the gather is two dependent
-// round trips into a tensor that is cold by then, this turns the second into an L1 hit.  Returns the sum of the taps so
-// that the loads stay in the program; the caller keeps it until the end of the kernel.
-template <int ND>
-__device__ __forceinline__ float touch_offsets(const Args &a, int n, int l, int id)
-{
-    const int W = a.W, H = a.H;
-    float acc = 0.f;
-    if (a.off_lowres) {
-        const int h4 = H / 4, w4 = W / 4;
-        const float *px = a.offs + ((size_t)n * ND * a.L + ND * l) * h4 * w4;
-        int x0, x1, y0, y1;
-        float l0, l1;
-        lin_coord((int)((unsigned)id % (unsigned)W), w4, x0, x1, l0, l1);
-        lin_coord((int)((unsigned)id / (unsigned)W), h4, y0, y1, l0, l1);
-#pragma unroll
-        for (int c = 0; c < ND; ++c) {
-            const float *pc = px + (size_t)c * h4 * w4;
-            acc += pc[(size_t)y0 * w4 + x0] + pc[(size_t)y0 * w4 + x1] + pc[(size_t)y1 * w4 + x0] + pc[(size_t)y1 * w4 + x1];
-        }
-    } else {
-        const float *px = a.offs + ((size_t)n * ND * a.L + ND * l) * ((long)H * W);
-#pragma unroll
-        for (int c = 0; c < ND; ++c) acc += px[(size_t)c * ((long)H * W) + id];
-    }
-    return acc;
-}
-
 // Rows of limb type `l` of image `n` by one GROUP of lanes (a wave, or half a wave when K <= 32; `lane` = 0..GROUP-1
 // within the group, the groups of a wave may work on different limb types).  sf/idf and st/idt: the k best (score, flat
 // index) of the limb's from- and to-joint planes (any address space; IdxT = int64_t in global memory, int in LDS).

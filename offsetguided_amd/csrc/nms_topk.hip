@@ -66,9 +66,6 @@ namespace {
                           // decode pipeline the batch has just been written by K1a and sits in the Infinity Cache: there nt loads cost
                           // 60 us (66 behind the backbone) against 57 -- tools/k1_bench.py, every policy (sc0, sc1, nt, combinations)
 #endif
-#ifndef OG_K1_TOUCH
-#define OG_K1_TOUCH 1   // merge stage requests the offset taps of every from-candidate that passes its filter (tools/build_variants.sh A/B)
-#endif
 #ifndef OG_K1_BAND_PF
 #define OG_K1_BAND_PF 3
 #endif
@@ -132,9 +129,11 @@ struct NoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <int VEC, int PF, class Emit, class Begin = NoHook, class End = NoHook>
+// `mid` runs once, between the issue of the first rows' loads and their first use: set-up work that has a memory round trip of
+// its own (the band kernel's workspace check) waits beside the rows instead of in front of them.
+template <int VEC, int PF, class Emit, class Begin = NoHook, class End = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g, Emit &&emit, Begin &&iter_begin = NoHook(),
-                                           End &&iter_end = NoHook())
+                                           End &&iter_end = NoHook(), Mid &&mid = NoHook())
 {
     const int H = g.plane_rows, W = g.plane_cols;
     const uint32_t row_bytes = (uint32_t)W * 4u;
@@ -167,6 +166,8 @@ __device__ __forceinline__ void walk_panel(const float *plane, const TileGeom &g
         q[u] = load_row(g.r0 + 1 + u);
         __builtin_amdgcn_sched_barrier(0);
     }
+    mid(0);
+    __builtin_amdgcn_sched_barrier(0);
     Px<VEC> hm_a = hmax3<VEC>(top);
     Px<VEC> hm_b = hmax3<VEC>(v_b);
     for (int r = g.r0; r < g.r1; r += PF) {
@@ -440,14 +441,10 @@ struct WaveSeg {
 // zero-padded by their writers (a key is never zero).  `all` / `flt`: n_all = nlists * k keys each, in LDS;
 // `s_bound` / `s_nf`: the group's own shared words.  emit(rank, score, flat index) receives the k best in any order.
 // SC1: the band lists were written in THIS launch by other workgroups (sc1 stores): read them with sc1 loads.
-struct NoPass {
-    __device__ __forceinline__ void operator()(uint64_t) const {}
-};
-template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit, class Pass = NoPass>
+template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit>
 __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uint64_t *all,
                                             uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
-                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit,
-                                            Pass &&on_pass = NoPass())
+                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit)
 {
     const int n_all = nlists * k, lane = tid & 63;
     // All of a thread's keys are requested before the first one is used (one memory round trip, not one per key), and
@@ -481,10 +478,7 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
     // B) keys >= bound (order does not matter: ranks are recomputed)
     for (int i = tid; i < n_all; i += nthr) {
         const uint64_t key = all[i];
-        if (key != 0ull && key >= bound) {
-            flt[atomicAdd(s_nf, 1)] = key;
-            on_pass(key);   // (a superset of the k best, known one ranking step before them)
-        }
+        if (key != 0ull && key >= bound) flt[atomicAdd(s_nf, 1)] = key;
     }
     __syncthreads();
     MERGE_STAMP(5);
@@ -596,16 +590,24 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     const int hmode = helper;   // bit 0: helper wave present; bit 3: debug statistics (tools/)
     helper &= 1;
     const int nstream = (blockDim.x >> 6) - helper;   // streaming waves
-    int *gslot = (NMS_MODE && helper && *ws_magic == magic) ? hist_all + (size_t)plane * max_bands : nullptr;
-    seg.hist = gslot ? s_hist : nullptr;
+    // The workspace check (one memory round trip) and the LDS set-up behind it run AFTER a streaming wave has issued the
+    // loads of its first rows (walk_panel's `mid`): the stream starts one round trip earlier.  Every wave passes through
+    // `setup` exactly once (it holds a workgroup barrier).
+    int *gslot = nullptr;
+    seg.hist = nullptr;
     int *s_done = s_tau_p + 1;
-    if (gslot) {
-        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
-        if (threadIdx.x == 0) { s_tau = 1; *s_done = 0; }
-        __syncthreads();
-    }
+    auto setup = [&](int) {
+        gslot = (NMS_MODE && helper && *ws_magic == magic) ? hist_all + (size_t)plane * max_bands : nullptr;
+        seg.hist = gslot ? s_hist : nullptr;
+        if (gslot) {
+            for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+            if (threadIdx.x == 0) { s_tau = 1; *s_done = 0; }
+            __syncthreads();
+        }
+    };
     const int lane_id = threadIdx.x & 63;
     if (helper && wave == nstream) {
+        setup(0);
         if (gslot) {
             const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(gslot, 0, nbands * 4, 0x00020000);
             const int t_band = (k + 3) / 4, need = (k + t_band - 1) / t_band;
@@ -731,8 +733,12 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     };
     BAND_STAMP(1);
     if (wave < nstream) {  // threshold refresh at the END of each iteration (see walk_panel)
-        if constexpr (FUSED) walk_panel_fused<PF>(src, H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
-        else walk_panel<VEC, PF>(src, g, emit_fn, NoHook(), iter_begin);
+        if constexpr (FUSED) {
+            setup(0);
+            walk_panel_fused<PF>(src, H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
+        } else {
+            walk_panel<VEC, PF>(src, g, emit_fn, NoHook(), iter_begin, setup);
+        }
     }
     if (gslot && lane_id == 0 && wave < nstream && !reported) atomicAdd(s_done, 1);
     if ((hmode & 8) && hist_all && lane_id == 0 && wave < nstream) {  // debug: pushes / final threshold / waves, kept in the unused tail of the slot region
@@ -960,7 +966,6 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ h
     }
     float *os = limb ? ls + half * Kp : out_scores + (size_t)plane * k;
     int *oi32 = li + half * Kp;
-    float touched = 0.f;
     int64_t *oi64 = out_inds + (size_t)plane * k;
     const int first = bm_start(bm, plane), nlists = (bm_start(bm, plane + 1) - first) * wl;
     merge_plane<true, false>(band_keys + (size_t)first * wl * k, all, flt, &s_bound[half],
@@ -968,20 +973,12 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ h
                              [&](int rank, float v, long idx) {
                                  if (limb) { os[rank] = v; oi32[rank] = (int)idx; }
                                  else if (live) { os[rank] = v; oi64[rank] = (int64_t)idx; }
-                             },
-                             [&](uint64_t key) {   // from-candidates of a limb: their offset taps are on the way before they are ranked
-#if OG_K1_TOUCH
-                                 if (limb && half == 0) touched += og_collect::touch_offsets<ND>(a, n, l, (int)og_key_index(key));
-#else
-                                 (void)key;
-#endif
                              });
     if (!limb) return;
     __syncthreads();
     MERGE_STAMP(1);
     if (threadIdx.x < 64) og_collect::limb_rows<ND, int>(a, n, l, threadIdx.x, ls, li, ls + Kp, li + Kp, sm);
     MERGE_STAMP(2);
-    if (touched == 1.0e38f) sm[threadIdx.x & 1] = touched;   // never true for sums of finite taps worth using: keeps the loads alive
 }
 
 // dynamic LDS the tail of band_topk_kernel<..., TAIL> needs (see its carve-up), for a workgroup of `waves` waves
@@ -1021,9 +1018,11 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     rows = min(rows, H);
     p->rows = rows;
     p->nbands = (H + rows - 1) / rows;
-    // Work items: the multiple of the CU count nearest to planes x nbands, when that keeps the bands within a quarter of the
-    // tuned height (OG_K1_BAND_WGS_PER_CU: 0 = equal bands of OG_NMS_ROWS rows, n > 0 = n workgroups per CU)
-    static const int per_cu_env = env_int("OG_K1_BAND_WGS_PER_CU", -1);
+    // Work items: equal bands of OG_NMS_ROWS rows, or (OG_K1_BAND_WGS_PER_CU: n > 0 = n workgroups per CU, -1 = the multiple of
+    // the CU count nearest to planes x nbands) a balanced map when that keeps the bands within a quarter of the tuned height.
+    // Stand-alone on HBM-cold data the balanced map is 1 us faster (no fifth workgroup on every fourth CU); in the decode
+    // pipeline, where the batch has just been written, equal bands measured 0-2 us faster: the default.
+    static const int per_cu_env = env_int("OG_K1_BAND_WGS_PER_CU", 0);
     p->bm = BandMap{(int)planes, p->nbands, 0};
     if (per_cu_env != 0 && planes < (1l << 12) && H < (1 << 20)) {   // (planes x work items and bands x H stay below 2^32)
         const long cus = device_cu_count(), uniform = planes * p->nbands;

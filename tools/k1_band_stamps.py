@@ -15,7 +15,7 @@ from offsetguided_amd.config import coco_data as cd  # noqa: E402
 from tools.k1_bench import load  # noqa: E402
 
 
-def report(buf, n_limb_wgs, title, wbuf=None):
+def report(buf, n_limb_wgs, title, wbuf=None, launches=1):
     st = buf.reshape(2048, 8).astype(np.float64)
     nb = int((st[:1100, 0] > 0).sum())   # workgroups of the band kernel
     band, mrg = st[:nb], st[1100:1100 + n_limb_wgs]
@@ -24,6 +24,7 @@ def report(buf, n_limb_wgs, title, wbuf=None):
     m = (mrg[:, :3] - t0) / 100.0
     mi = (mrg[:, 3:6] - t0) / 100.0   # inside merge_plane: keys in LDS, bound known, filtered
     nf = mrg[:, 7]
+    nz = mrg[:, 6]
     q = lambda v: f'min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}'
     print(title)
     for j, nm in enumerate(['band entry', 'set-up done', 'stream done', 'compacted', 'list stored']):
@@ -49,7 +50,7 @@ def report(buf, n_limb_wgs, title, wbuf=None):
     print(f'   stream duration {q(b[:, 2] - b[:, 1])};  compaction {q(b[:, 3] - b[:, 2])};  merge+store {q(b[:, 4] - b[:, 3])}')
     for j, nm in enumerate(['merge entry', 'planes merged', 'rows written']):
         print(f'   {nm:13s} {q(m[:, j])}')
-    print(f'   merge: entry -> keys in LDS {q(mi[:, 0] - m[:, 0])};  -> bound {q(mi[:, 1] - mi[:, 0])};  -> filtered {q(mi[:, 2] - mi[:, 1])};  -> ranked + emitted {q(m[:, 1] - mi[:, 2])};  keys past the filter {q(nf)}')
+    print(f'   merge: entry -> keys in LDS {q(mi[:, 0] - m[:, 0])};  -> bound {q(mi[:, 1] - mi[:, 0])};  -> filtered {q(mi[:, 2] - mi[:, 1])};  -> ranked + emitted {q(m[:, 1] - mi[:, 2])};  keys past the filter {q(nf)};  non-zero keys of the plane (accumulated over launches / launches) {q(nz / max(1, launches))}')
     print(f'   merge duration {q(m[:, 1] - m[:, 0])};  pairing {q(m[:, 2] - m[:, 1])};  gap last band -> first merge {m[:, 0].min() - b[:, 4].max():.2f}')
 
 
@@ -92,7 +93,7 @@ def main():
         wbuf = np.zeros(2048 * 16, np.int64)
         lib.og_k1_wave_stamps.argtypes = [C.c_void_p]
         lib.og_k1_wave_stamps(wbuf.ctypes.data)
-        report(buf, n * L, f'launch {it}:', wbuf)
+        report(buf, n * L, f'launch {it}:', wbuf, it + 1)
         if os.environ.get('OG_K1_HELPER') == '9':   # debug statistics of the band kernel (helper bit 3), accumulated over the launches
             off = 65536 + 256 + (n * c * 256 - 16) * 4
             d = ws[off:off + 16].view(torch.int32).cpu().numpy()
