@@ -40,7 +40,11 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef OG_K3_THREADS
+#define OG_K3_THREADS 1024
+#endif
+constexpr int kThreads = OG_K3_THREADS;   // a multiple of 256
+constexpr int kScoreThreads = 256;         // threads that score the rows at the end (17 floats of LDS scratch each)
 
 #ifdef OG_K3_STAMPS
 __device__ unsigned long long g_k3_stamps[16];
@@ -128,7 +132,7 @@ greedy_group_kernel(GroupArgs A)
     int *r_b = (int *)p;         p += mmax;                // phase-B last column per logical row
     int *r_p = (int *)p;         p += mmax;                // last merge partner
     int *r_d = (int *)p;         p += mmax;                // deleted by a merge / dropped by the final threshold
-    float *s_vals = p;           p += kThreads * 17;       // per-thread scratch for the final mean
+    float *s_vals = p;           p += kScoreThreads * 17;   // per-thread scratch for the final mean
     float *sub_lds = p;
     float *sub_glb = A.gsub + (size_t)img * mmax * rowf;
 #define sub (GSUB ? sub_glb : sub_lds)
@@ -327,10 +331,11 @@ greedy_group_kernel(GroupArgs A)
             if (m0 >= 2) {
                 // 16 x 16 tiles of (a, b) over the upper triangle: no index decoding, no divisions (one pair per lane in row-major
                 // order of the triangle needs a third fewer rounds at 30 rows, but its index decoding costs more than that)
-                const int ta_n = (m0 + 15) >> 4;
+                constexpr int TA = kThreads >> 4;   // rows a per tile (16 with 256 threads), 16 rows b
+                const int ta_n = (m0 + TA - 1) / TA, tb_n = (m0 + 15) >> 4;
                 for (int ta = 0; ta < ta_n; ++ta)
-                    for (int tb = ta; tb < ta_n; ++tb) {
-                        const int a = (ta << 4) + (tid >> 4), b = (tb << 4) + (tid & 15);
+                    for (int tb = (ta * TA) >> 4; tb < tb_n; ++tb) {
+                        const int a = ta * TA + (tid >> 4), b = (tb << 4) + (tid & 15);
                         if (a < b && b < m0) {
                             const int pa = order[a], pb = order[b];
                             typedef int v4i __attribute__((ext_vector_type(4)));
@@ -437,7 +442,7 @@ greedy_group_kernel(GroupArgs A)
     const int M = M_rows;
     if (tid == 0) s_kept = 0;
     __syncthreads();
-    for (int m = tid; m < M; m += kThreads) {
+    for (int m = tid; m < M && tid < kScoreThreads; m += kScoreThreads) {
         const int ph = order[m];
         float *v = s_vals + (size_t)tid * 17;
         int n = 0;
@@ -486,7 +491,7 @@ size_t staging_bytes(int L, int K, int mmax)
 {
     const size_t lk = (size_t)L * K;
     return (size_t)mmax * kIdPitch * 4 + (size_t)mmax * 8 +
-           (lk * 11 + lk * 5 + L + (size_t)K * 5 + (size_t)mmax * 5 + kThreads * 17) * 4 + 64 + 6 * 16;
+           (lk * 11 + lk * 5 + L + (size_t)K * 5 + (size_t)mmax * 5 + kScoreThreads * 17) * 4 + 64 + 6 * 16;
 }
 
 }  // namespace
