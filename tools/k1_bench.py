@@ -60,6 +60,7 @@ def bench_inputs(dev, n_rot=3, batch=8, size=640):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bench-inputs', action='store_true', help='decoder inputs as in bench.py (network head outputs + synthetic maps) instead of the synthetic maps alone')
+    ap.add_argument('--forms', nargs='*', default=['single', 'two', 'in-band', 'three'], help='which forms of K1 to time (PMC passes: --forms two = the default form only)')
     ap.add_argument('--libs', nargs='*', default=[_lib.LIB_PATH])
     ap.add_argument('--iters', type=int, default=40)
     ap.add_argument('--batch', type=int, default=8)
@@ -129,7 +130,7 @@ def main():
                                                      w, _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(limbs3), sp), lib)
 
         ok = True
-        for i in range(a.rotate):
+        for i in range(a.rotate if len(a.forms) == 4 else 0):
             single(i)
             three(i)
             two(i)
@@ -159,8 +160,9 @@ def main():
             t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
             return float(np.median(t)), float(t.min())
 
-        res = {'single cold': timed(single), 'two cold': timed(two), 'in-band cold': timed(inband), 'three cold': timed(three),
-               'single after K1a': timed(single, k1a), 'two after K1a': timed(two, k1a), 'in-band after K1a': timed(inband, k1a), 'three after K1a': timed(three, k1a)}
+        fns = {'single': single, 'two': two, 'in-band': inband, 'three': three}
+        res = {f'{f} cold': timed(fns[f]) for f in a.forms}
+        res.update({f'{f} after K1a': timed(fns[f], k1a) for f in a.forms})
         if a.burst:
             ga = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
             gb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
