@@ -210,3 +210,42 @@ def test_random_shapes_all_forms_agree(dev):
             assert int(ws[:61440].view(torch.int32).abs().sum()) == 0, (it, flags)
         done += 1
     assert done >= 30
+
+
+@pytest.mark.parametrize("knobs", [{"OG_K1_BAND_WGS_PER_CU": "-1"}, {"OG_K1_BAND_WGS_PER_CU": "5"}, {"OG_K1_WAVE_LISTS": "0"}])
+def test_band_layout_knobs(dev, knobs):
+    """The kept A/B layouts of the band kernel (read once per process): balanced work-item map (planes cut into b or b+1
+    bands, a multiple of the CU count), one list per band instead of one per streaming wave -- the random-shape and the
+    full-size tests again in a child process, bit for bit against the separate entry points."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_random_shapes_all_forms_agree or test_full_size_batch_repeated or test_degenerate_planes"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
+def test_offset_planes_full_size(dev):
+    """Planes that sit on a large positive or negative offset with large-scale structure (what a random-init network's heads
+    add to the maps in bench.py): every pixel above the starting threshold, or fewer than k positive peaks in the plane (the
+    merge's zero-fill path) -- bs8 640x640, flags 0 against the separate entry points, bit for bit, three times."""
+    n, h, w, k = 8, 640, 640, 32
+    hm, off = synth.synth_batch(11, n, h, w)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, h // 4, dtype=np.float32), np.linspace(-1, 1, w // 4, dtype=np.float32), indexing='ij')
+    rng = np.random.default_rng(3)
+    for i in range(n):
+        for c in range(17):
+            a, b, o = rng.uniform(-0.4, 0.4, 3)
+            hm[i, c] += (o + a * yy + b * xx).astype(np.float32)   # some planes end up negative nearly everywhere
+    hr = torch.from_numpy(oracle.bicubic4(hm)).to(dev)
+    t_off = torch.from_numpy(off).to(dev)
+    l3, s3, i3 = run_three(hr, t_off, k, dev)
+    ws = None
+    for _ in range(3):
+        l, s, i, ws = run_single(hr, t_off, k, dev, ws=ws, single=0)
+        assert torch.equal(l, l3) and torch.equal(s, s3) and torch.equal(i, i3)
+    few = int(((torch.from_numpy(oracle.hmp_nms(hr.cpu().numpy()[:1])) > 0).sum(dim=(2, 3)) < k).sum())
+    assert few >= 1, "the case is meant to hold planes with fewer than k positive peaks"
