@@ -45,26 +45,41 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
     t /= tiles_x;
     const int ty = t % tiles_y, n = t / tiles_y;
 
-    // ---- weights: 128 rows x 28 16-B chunks -> padded rows
-    for (int i = tid; i < kCout * 28; i += 256) {
-        const int r = i / 28, c = i - r * 28;
-        *reinterpret_cast<u16x8 *>(wS + r * kWPitch + c * 16) = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
-    }
-    // ---- input tile: fp32 planes -> 4-channel bf16 pixels, zero outside the image (pad 3)
+    // ---- operands: every load of a thread is issued before the first one is used.  (As loops with the LDS store inside,
+    // the compiler waited for each load: 14 + 6 serialised memory round trips per workgroup, ~20 us of its ~25 us life --
+    // 113 us for the layer.)  The input pixels (HBM) go first, the weights (L2-resident after the first workgroups) behind.
     const size_t plane = (size_t)H * W;
     const float *src = img + (size_t)n * 3 * plane;
     const int iy0 = ty * 32 - 3, ix0 = tx * 32 - 3;
-    for (int i = tid; i < kInH * kInW; i += 256) {
-        const int r = i / kInW, c = i - r * kInW;
+    constexpr int kInIter = (kInH * kInW + 255) / 256;   // 6
+    constexpr int kWIter = kCout * 28 / 256;             // 14
+    static_assert(kCout * 28 % 256 == 0, "weight chunks divide among the threads");
+    float pin_f[kInIter][3];
+#pragma unroll
+    for (int u = 0; u < kInIter; ++u) {
+        const int i = tid + 256 * u, r = i / kInW, c = i - r * kInW;
         const int y = iy0 + r, x = ix0 + c;
-        u16x4 px = {0, 0, 0, 0};
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const size_t o = (size_t)y * W + x;
-            px[0] = f2bf(src[o]);
-            px[1] = f2bf(src[plane + o]);
-            px[2] = f2bf(src[2 * plane + o]);
-        }
-        *reinterpret_cast<u16x4 *>(inS + i * 8) = px;
+        const bool ok = i < kInH * kInW && y >= 0 && y < H && x >= 0 && x < W;
+        const size_t o = ok ? (size_t)y * W + x : 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) pin_f[u][ch] = ok ? src[ch * plane + o] : 0.f;
+    }
+    u16x8 wreg[kWIter];
+#pragma unroll
+    for (int u = 0; u < kWIter; ++u) {
+        const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
+        wreg[u] = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < kInIter; ++u) {   // fp32 planes -> 4-channel bf16 pixels, zero outside the image (pad 3)
+        const int i = tid + 256 * u;
+        const u16x4 px = {f2bf(pin_f[u][0]), f2bf(pin_f[u][1]), f2bf(pin_f[u][2]), 0};
+        if (i < kInH * kInW) *reinterpret_cast<u16x4 *>(inS + i * 8) = px;
+    }
+#pragma unroll
+    for (int u = 0; u < kWIter; ++u) {    // 128 rows x 28 16-B chunks -> padded rows
+        const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
+        *reinterpret_cast<u16x8 *>(wS + r * kWPitch + c * 16) = wreg[u];
     }
     __syncthreads();
 
