@@ -290,6 +290,12 @@ int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packe
 size_t og_conv3x3_tiled_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
                           int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+/* The last convolution below an hourglass merge and the merge itself in one launch (kp_module.forward, models/hourglass_104.py:
+ * 170-176: up2 = upsample(low3); return up1 + up2): up (N,2H,2W,Cout), holding up1, += nearest_x2(act(conv3x3(x) + bias + skip)),
+ * the convolution's result rounded to 16 bits first -- og_conv3x3_tiled_bf16 followed by og_upsample2_add_bf16, bit for bit; the
+ * (N,H,W,Cout) tensor in between is never written.  Shapes and workspace as og_conv3x3_tiled_bf16. */
+int og_conv3x3_tiled_up2_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *up, int N, int H,
+                              int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 /* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
  * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
  * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.
@@ -328,6 +334,8 @@ int og_stem7x7_f16(const float *images, const void *w_packed, const float *bias,
 int og_conv3x3_f16(const void *x, const void *w, const float *bias, const void *skip, void *out, int N, int H, int W,
                    int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv3x3_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int H,
+                         int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv3x3_tiled_up2_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *up, int N, int H,
                          int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
 int og_conv3x3s2_tiled_f16(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N, int Hin,
                            int Win, int Cin, int Cout, int relu, void *stream);

@@ -51,6 +51,7 @@ struct ConvArgs {
     const float *bias;           // fp32[Cout]
     const unsigned short *skip;  // (N,H,W,Cout) bf16 or null
     unsigned short *out;         // (N,H,W,Cout) bf16
+    unsigned short *up;          // tiled kernel, or null: (N,2H,2W,Cout) updated in place, up += nearest_x2(result); `out` is not written
     float *partial;              // [tile][ksplit][NT*MT][256 lanes] x 4 fp32 slabs (ksplit > 1)
     int *counters;               // [tiles] arrival tickets, zero between launches
     const unsigned short *zero;  // >= 16 B of zeros
@@ -1144,12 +1145,12 @@ OG_API int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void
 }
 #endif
 
-OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N,
-                                        int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes,
-                                        void *stream)
+namespace {
+int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, const float *bias, const void *skip, void *out, void *up,
+                       int N, int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
 {
-    const char *name = OG_LP_STR("og_conv3x3_tiled");
-    OG_REQUIRE(x && w_packed && bias && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(x && w_packed && bias && (out || up), OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(!up || (uintptr_t)up % 16 == 0, OG_EINVAL, "%s: `up` must be 16-byte aligned", name);
     OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
     const long M = (long)N * H * W;
     OG_REQUIRE(M * (long)Cin < (1l << 30) && M * (long)Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
@@ -1158,7 +1159,7 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
                "(got %dx%d, %d -> %d)", name, H, W, Cin, Cout);
     ConvArgs h = {};
     h.x = (const unsigned short *)x; h.w = (const unsigned short *)w_packed; h.bias = bias;
-    h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out;
+    h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.up = (unsigned short *)up;
     h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
     h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
     h.x_bytes = (int)(M * Cin * 2);
@@ -1232,6 +1233,29 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, con
 #undef TILED_LAUNCH_NW
     OG_LAUNCH_CHECK(name);
     return OG_OK;
+}
+}  // namespace
+
+OG_API int OG_LP_NAME(og_conv3x3_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out, int N,
+                                        int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes,
+                                        void *stream)
+{
+    return conv3x3_tiled_impl(OG_LP_STR("og_conv3x3_tiled"), x, w_packed, bias, skip, out, nullptr, N, H, W, Cin, Cout, relu, workspace,
+                              workspace_bytes, stream);
+}
+
+// The last convolution below an hourglass merge and the merge itself (kp_module.forward: up2 = upsample(low3); up1 + up2,
+// models/hourglass_104.py:170-176) in one launch: up (N,2H,2W,Cout) += nearest_x2(act(conv3x3(x) + bias + skip)), the
+// convolution's result rounded to 16 bits first (= og_conv3x3_tiled_* followed by og_upsample2_add_*, bit for bit).
+// The (N,H,W,Cout) tensor in between is never written.
+OG_API int OG_LP_NAME(og_conv3x3_tiled_up2)(const void *x, const void *w_packed, const float *bias, const void *skip, void *up, int N,
+                                            int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes,
+                                            void *stream)
+{
+    const char *name = OG_LP_STR("og_conv3x3_tiled_up2");
+    OG_REQUIRE(up, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE((long)N * H * W * 4 * Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
+    return conv3x3_tiled_impl(name, x, w_packed, bias, skip, nullptr, up, N, H, W, Cin, Cout, relu, workspace, workspace_bytes, stream);
 }
 
 OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out,

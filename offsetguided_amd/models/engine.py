@@ -93,6 +93,7 @@ BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
 # submitted deepest level first, the order in which the trunk joins them on its way up.
 SIDE_SHARED = int(os.environ.get('OG_ENGINE_SIDE_SHARED', '0'))
 _shared_side = {}
+CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
 BRANCH_MIN_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MIN_DEPTH', '0'))   # levels above this depth run up1 in the trunk, unforked
 _pending_branches = []
 _conv_ws = {}
@@ -227,6 +228,33 @@ class _Conv:
                                                              cout, int(self.relu), _lib.stream_ptr(x.device)), lib)
         return out
 
+    def up2_ok(self, x):
+        """This layer can run as og_conv3x3_tiled_up2_* on x: the merge of the hourglass level above rides on its epilogue."""
+        n, c, h, w = x.shape
+        return (CONV_UP2 and self.hip3x3 and self.stride[0] == 1 and (CONV_TILED & 1) and n * h * w >= CONV_TILED_MIN_PIXELS
+                and self.w.shape[0] % 128 == 0 and not _WHATIF and x.is_cuda
+                and _lib.load().og_conv3x3_tiled_supported(n, h, w, c, self.w.shape[0]))
+
+    def up2(self, x, skip, up):
+        """up += nearest_x2(act(conv(x) + bias + skip)) in one launch (up: (N, Cout, 2H, 2W) channels-last, in place)."""
+        n, c, h, w = x.shape
+        cout = self.w.shape[0]
+        assert x.is_contiguous(memory_format=torch.channels_last) and up.is_contiguous(memory_format=torch.channels_last)
+        assert tuple(up.shape) == (n, cout, 2 * h, 2 * w)
+        if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+        lib = _lib.load()
+        if self.w_tiled is None:
+            assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+            self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
+            _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 0, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
+        need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, cout)
+        ws = _conv3x3_workspace(x.device, need) if need else None
+        _lib.check(_lib.lp(lib, 'og_conv3x3_tiled_up2', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
+                                                                 _lib.ptr(skip) if skip is not None else None, _lib.ptr(up), n, h, w,
+                                                                 c, cout, int(self.relu), _lib.ptr(ws) if need else None,
+                                                                 ws.numel() if need else 0, _lib.stream_ptr(x.device)), lib)
+
     def _hip(self, x, skip):
         n, c, h, w = x.shape
         cout, st = self.w.shape[0], self.stride[0]
@@ -273,7 +301,9 @@ class _Residual:
                 self.w_cat = torch.cat([self.c2.w.permute(0, 2, 3, 1).reshape(cout, -1),
                                         self.skip.w.reshape(cout, -1)], 1).contiguous()
 
-    def __call__(self, x):
+    def __call__(self, x, merge_up=None):
+        """-> the block's output; with `merge_up` (the up1 tensor of the hourglass level above, channels-last) and conv2 on
+        the tiled kernel: merge_up += nearest_x2(output) in conv2's epilogue, returns None (the output is never written)."""
         y = self.c1(x)
         n, c, h, w = y.shape
         if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS and not _WHATIF:
@@ -284,6 +314,9 @@ class _Residual:
             shortcut = self.skip.pointwise(x, bias=False)      # raw projection: its bias rides on conv2's epilogue
         else:
             shortcut = self.skip.raw(x)
+        if merge_up is not None and self.c2.up2_ok(y):
+            self.c2.up2(y, shortcut, merge_up)
+            return None
         return self.c2(y, skip=shortcut)
 
     def _proj(self, y, x):
@@ -318,9 +351,10 @@ class _Level:
                      else _seq(m.low2, dtype, fused))
 
     def _lower(self, x):
+        """-> the input of low3's LAST residual (that one runs after the join: the merge may ride on its epilogue)"""
         low = _run(self.low1, x)
         low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
-        return _run(self.low3, low)
+        return _run(self.low3[:-1], low)
 
     def __call__(self, x):
         if BRANCHES and x.is_cuda and BRANCH_MIN_DEPTH <= self.depth <= BRANCH_MAX_DEPTH:
@@ -365,6 +399,9 @@ class _Level:
         else:
             low = self._lower(x)
             up = _run(self.up1, x)
+        low = self.low3[-1](low, merge_up=up if self.fused and up.is_contiguous(memory_format=torch.channels_last) else None)
+        if low is None:
+            return up   # up += nearest_x2(low3(low)) happened in the last convolution's epilogue
         if self.fused:  # up += nearest_x2(low) in one pass
             n, c, h, w = up.shape
             lib = _lib.load()

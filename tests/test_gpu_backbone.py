@@ -387,6 +387,43 @@ def test_conv3x3_tiled_repeated_full_size(dev):
     assert d <= 2 ** -6 * max(1.0, old.float().abs().max().item()), d     # same operands, different fp32 summation order
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 256), (1, 80, 80, 256, 256), (3, 40, 40, 384, 256), (2, 12, 40, 256, 384),
+                                   (8, 20, 20, 384, 384), (2, 16, 48, 64, 128)])
+def test_conv3x3_tiled_up2_equals_conv_then_upsample_add(dev, shape, dtype):
+    """og_conv3x3_tiled_up2_* (the hourglass merge on the epilogue of the convolution below it, models/hourglass_104.py:170-176)
+    == og_conv3x3_tiled_* followed by og_upsample2_add_*, bit for bit -- every tile shape, K-split shapes included, with and
+    without the residual, twice."""
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    assert lib.og_conv3x3_tiled_supported(n, h, w, cin, cout) > 0
+    g = torch.Generator(device='cpu').manual_seed(h * 77 + cout)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    skip = torch.randn(n, cout, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    up1 = torch.randn(n, cout, 2 * h, 2 * w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+    need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, cin, cout)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev) if need else None
+    wsp, st = (_lib.ptr(ws) if need else None), _lib.stream_ptr(dev)
+    for use_skip, relu in ((True, 1), (False, 0)):
+        sk = _lib.ptr(skip) if use_skip else None
+        low = torch.empty_like(skip)
+        _lib.check(_lib.lp(lib, 'og_conv3x3_tiled', dtype)(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), sk, _lib.ptr(low), n, h, w,
+                                                           cin, cout, relu, wsp, need, st), lib)
+        want = up1.clone(memory_format=torch.preserve_format)
+        _lib.check(_lib.lp(lib, 'og_upsample2_add', dtype)(_lib.ptr(want), _lib.ptr(low), n, 2 * h, 2 * w, cout, st), lib)
+        for _ in range(2):
+            got = up1.clone(memory_format=torch.preserve_format)
+            _lib.check(_lib.lp(lib, 'og_conv3x3_tiled_up2', dtype)(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), sk, _lib.ptr(got), n, h,
+                                                                   w, cin, cout, relu, wsp, need, st), lib)
+            assert torch.equal(got, want)
+        assert not torch.equal(want, up1)
+
+
 def test_conv3x3_halo_kernel_several_items_per_workgroup(dev):
     """OG_CONV_HALO_ITEMS (read once per process): the halo-kernel tests again in a child process with 3 work items per
     workgroup forced -- cross-item prefetch, two-half epilogue, residual re-initialisation."""
