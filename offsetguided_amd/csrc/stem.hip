@@ -18,6 +18,10 @@
 
 namespace {
 
+#ifndef OG_STEM_ABL
+#define OG_STEM_ABL 0   // timing experiments (wrong results): 1 no output stores, 2 no input loads, 4 no weight loads, 8 no MFMA
+#endif
+
 typedef lp8 bf16x8;   // 8 x 16-bit operands of one MFMA fragment (lp_dtype.h)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
@@ -62,13 +66,14 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
         const bool ok = i < kInH * kInW && y >= 0 && y < H && x >= 0 && x < W;
         const size_t o = ok ? (size_t)y * W + x : 0;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) pin_f[u][ch] = ok ? src[ch * plane + o] : 0.f;
+        for (int ch = 0; ch < 3; ++ch) pin_f[u][ch] = (ok && !(OG_STEM_ABL & 2)) ? src[ch * plane + o] : 0.f;
     }
     u16x8 wreg[kWIter];
 #pragma unroll
     for (int u = 0; u < kWIter; ++u) {
         const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
-        wreg[u] = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
+        if (OG_STEM_ABL & 4) wreg[u] = (u16x8){1, 2, 3, 4, 5, 6, 7, (unsigned short)tid};
+        else wreg[u] = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
     }
 #pragma unroll
     for (int u = 0; u < kInIter; ++u) {   // fp32 planes -> 4-channel bf16 pixels, zero outside the image (pad 3)
@@ -109,7 +114,10 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[nn][m] = OG_LP_MFMA(wf[nn], pf[m], acc[nn][m]);
+                for (int m = 0; m < 4; ++m) {
+                    if (OG_STEM_ABL & 8) acc[nn][m][0] += (float)wf[nn][0] * (float)pf[m][0];
+                    else acc[nn][m] = OG_LP_MFMA(wf[nn], pf[m], acc[nn][m]);
+                }
         }
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {  // bias + ReLU + the one rounding
@@ -140,7 +148,8 @@ stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__
     for (int i = 0; i < 16; ++i) {
         const int g = tid + 256 * i, px = g >> 4, cg = g & 15;
         const size_t off = (tile_px + (size_t)(px >> 4) * Wo + (px & 15)) * kCout + cg * 8;
-        *reinterpret_cast<u16x8 *>(out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
+        if (!(OG_STEM_ABL & 1) || off == 12345)
+            *reinterpret_cast<u16x8 *>(out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
     }
 }
 
