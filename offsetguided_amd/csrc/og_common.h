@@ -27,6 +27,20 @@ void og_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
         }                                                                          \
     } while (0)
 
+// Compute units of the current device (256 on MI355X; 256 when the query fails), asked once per process and device.
+static inline int og_cu_count()
+{
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 static inline size_t og_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // hipFuncSetAttribute applies to the CURRENT device: a process that drives several devices must apply it on each one.

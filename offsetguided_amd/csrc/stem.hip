@@ -31,125 +31,140 @@ constexpr int kCout = 128, kKRow = 32, kK = 7 * kKRow;          // 224
 constexpr int kWPitch = kK * 2 + 16;                            // 464 B per cout row (29 16-B slots: odd)
 constexpr int kInW = 38, kInH = 37;                             // input tile incl. halo (+1 pad column)
 constexpr int kWBytes = kCout * kWPitch, kInBytes = kInH * kInW * 8;
-constexpr int kOPitch = kCout * 2 + 16;
-static_assert(256 * kOPitch <= kWBytes + kInBytes, "output staging reuses the operand LDS");
+constexpr int kOPitch = 64 * 2 + 16, kOBytes = 16 * kOPitch;     // per wave: one output row, 16 pixels x 64 couts (+ 16 B pad)
+static_assert(2 * (kWBytes + kInBytes + 4 * kOBytes) <= 160 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return f2lp(f); }   // (bf16, or fp16 in the -DOG_DT_F16 build)
 
+// Persistent form: a workgroup loads the 57 KB weight matrix into LDS ONCE and walks over tiles (grid = 2 workgroups per
+// CU); the next tile's input pixels are requested into registers before the current tile's MFMAs and go to LDS behind
+// them; results leave straight from the accumulators (a lane holds 4 consecutive couts of a pixel: 8-B stores, 32 B
+// contiguous per pixel and instruction, the eight fragments of a pixel complete its 256-B row) -- no output staging, so
+// the weights never have to be re-staged.  One tile per workgroup (the first form of this kernel) spent its time on
+// exactly that: timing builds without loads / stores / MFMA still took 38 of its 85 us.
 __global__ void __launch_bounds__(256, 2)
 stem7x7_kernel(const float *__restrict__ img, const unsigned short *__restrict__ wp, const float *__restrict__ bias,
-               unsigned short *__restrict__ out, int H, int W, int relu)
+               unsigned short *__restrict__ out, int H, int W, int relu, int n_tiles)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char *const wS = lds, *const inS = lds + kWBytes;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Ho = H >> 1, Wo = W >> 1, tiles_x = Wo >> 4, tiles_y = Ho >> 4;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, n = t / tiles_y;
-
-    // ---- operands: every load of a thread is issued before the first one is used.  (As loops with the LDS store inside,
-    // the compiler waited for each load: 14 + 6 serialised memory round trips per workgroup, ~20 us of its ~25 us life --
-    // 113 us for the layer.)  The input pixels (HBM) go first, the weights (L2-resident after the first workgroups) behind.
     const size_t plane = (size_t)H * W;
-    const float *src = img + (size_t)n * 3 * plane;
-    const int iy0 = ty * 32 - 3, ix0 = tx * 32 - 3;
     constexpr int kInIter = (kInH * kInW + 255) / 256;   // 6
     constexpr int kWIter = kCout * 28 / 256;             // 14
     static_assert(kCout * 28 % 256 == 0, "weight chunks divide among the threads");
-    float pin_f[kInIter][3];
-#pragma unroll
-    for (int u = 0; u < kInIter; ++u) {
-        const int i = tid + 256 * u, r = i / kInW, c = i - r * kInW;
-        const int y = iy0 + r, x = ix0 + c;
-        const bool ok = i < kInH * kInW && y >= 0 && y < H && x >= 0 && x < W;
-        const size_t o = ok ? (size_t)y * W + x : 0;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) pin_f[u][ch] = (ok && !(OG_STEM_ABL & 2)) ? src[ch * plane + o] : 0.f;
-    }
-    u16x8 wreg[kWIter];
-#pragma unroll
-    for (int u = 0; u < kWIter; ++u) {
-        const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
-        if (OG_STEM_ABL & 4) wreg[u] = (u16x8){1, 2, 3, 4, 5, 6, 7, (unsigned short)tid};
-        else wreg[u] = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < kInIter; ++u) {   // fp32 planes -> 4-channel bf16 pixels, zero outside the image (pad 3)
-        const int i = tid + 256 * u;
-        const u16x4 px = {f2bf(pin_f[u][0]), f2bf(pin_f[u][1]), f2bf(pin_f[u][2]), 0};
-        if (i < kInH * kInW) *reinterpret_cast<u16x4 *>(inS + i * 8) = px;
-    }
-#pragma unroll
-    for (int u = 0; u < kWIter; ++u) {    // 128 rows x 28 16-B chunks -> padded rows
-        const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
-        *reinterpret_cast<u16x8 *>(wS + r * kWPitch + c * 16) = wreg[u];
-    }
-    __syncthreads();
 
-    // ---- 7 k-steps (kernel rows); wave = 4 output rows x 16 columns; the 128 couts in two passes of 64 so that the
-    // accumulators take 64 registers, not 128 (with 128 the kernel needed 297 registers = one wave per SIMD, and no
-    // second workgroup on the CU to hide this one's load and store phases: 166 us).  Pass 0's results wait in registers
-    // as packed bf16 until the operands in LDS are no longer needed.
+    // every load of a thread is issued before the first one is used (as loops with the LDS store inside, the compiler
+    // waited for each load: 20 serialised memory round trips)
+    float pin_f[kInIter][3];
+    auto request_tile = [&](int t) {   // fp32 pixels of tile t's 37 x 38 input window into registers (zero outside the image: pad 3)
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const float *src = img + (size_t)n * 3 * plane;
+        const int iy0 = ty * 32 - 3, ix0 = tx * 32 - 3;
+#pragma unroll
+        for (int u = 0; u < kInIter; ++u) {
+            const int i = tid + 256 * u, r = i / kInW, c = i - r * kInW;
+            const int y = iy0 + r, x = ix0 + c;
+            const bool ok = i < kInH * kInW && y >= 0 && y < H && x >= 0 && x < W && !(OG_STEM_ABL & 2);
+            const size_t o = ok ? (size_t)y * W + x : 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) pin_f[u][ch] = ok ? src[ch * plane + o] : 0.f;
+        }
+    };
+    auto stage_tile = [&]() {          // -> 4-channel bf16 pixels in LDS
+#pragma unroll
+        for (int u = 0; u < kInIter; ++u) {
+            const int i = tid + 256 * u;
+            const u16x4 px = {f2bf(pin_f[u][0]), f2bf(pin_f[u][1]), f2bf(pin_f[u][2]), 0};
+            if (i < kInH * kInW) *reinterpret_cast<u16x4 *>(inS + i * 8) = px;
+        }
+    };
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    request_tile(t);
+    {
+        u16x8 wreg[kWIter];
+#pragma unroll
+        for (int u = 0; u < kWIter; ++u) {
+            const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
+            if (OG_STEM_ABL & 4) wreg[u] = (u16x8){1, 2, 3, 4, 5, 6, 7, (unsigned short)tid};
+            else wreg[u] = *reinterpret_cast<const u16x8 *>(wp + (size_t)r * kK + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < kWIter; ++u) {    // 128 rows x 28 16-B chunks -> padded rows
+            const int i = tid + 256 * u, r = i / 28, c = i - r * 28;
+            *reinterpret_cast<u16x8 *>(wS + r * kWPitch + c * 16) = wreg[u];
+        }
+    }
     const int fc = lane & 15, fk = lane >> 4;
+    unsigned char *const oS = inS + kInBytes + wave * kOBytes;   // this wave's output-row scratch
     const unsigned char *pin = inS + ((2 * (wave * 4)) * kInW + 2 * fc + 2 * fk) * 8;
     const unsigned char *pw = wS + fc * kWPitch + fk * 16;
-    u16x4 res[2][4][4];
+    f32x4 bv[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x4 acc[4][4];
+    for (int nn = 0; nn < 8; ++nn) bv[nn] = *reinterpret_cast<const f32x4 *>(bias + nn * 16 + fk * 4);
+
+    for (; t < n_tiles; t += gridDim.x) {
+        stage_tile();
+        __syncthreads();                       // tile t's pixels (and, the first time, the weights) are in LDS
+        const int tn = t + gridDim.x;
+        if (tn < n_tiles) request_tile(tn);    // in flight during this tile's MFMAs
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const size_t tile_px = ((size_t)n * Ho + ty * 16) * Wo + tx * 16;
+        // 7 k-steps (kernel rows); wave = 4 output rows x 16 columns; the 128 couts in two passes of 64 (64 accumulator
+        // registers, not 128: two workgroups per CU need the registers)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            bf16x8 pf[4], wf[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(pin + ((2 * m + ky) * kInW) * 8);
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[4][4];
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
-                wf[nn] = *reinterpret_cast<const bf16x8 *>(pw + (half * 4 + nn) * 16 * kWPitch + ky * 64);
 #pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
+                for (int m = 0; m < 4; ++m) acc[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (OG_STEM_ABL & 8) acc[nn][m][0] += (float)wf[nn][0] * (float)pf[m][0];
-                    else acc[nn][m] = OG_LP_MFMA(wf[nn], pf[m], acc[nn][m]);
+            for (int ky = 0; ky < 7; ++ky) {
+                bf16x8 pf[4], wf[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) pf[m] = *reinterpret_cast<const bf16x8 *>(pin + ((2 * m + ky) * kInW) * 8);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+                    wf[nn] = *reinterpret_cast<const bf16x8 *>(pw + (half * 4 + nn) * 16 * kWPitch + ky * 64);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (OG_STEM_ABL & 8) acc[nn][m][0] += (float)wf[nn][0] * (float)pf[m][0];
+                        else acc[nn][m] = OG_LP_MFMA(wf[nn], pf[m], acc[nn][m]);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {      // bias + ReLU + the one rounding; lane = pixel (row wave * 4 + m, column fc)
+                // one output row of the wave (16 pixels x 64 couts = 2 KB) through the wave's own LDS scratch: a lane holds 4
+                // consecutive couts of a pixel, the stores want 16 B per lane and 128 B contiguous per pixel (straight from
+                // the accumulators -- 8-B stores, 32 B per pixel and instruction -- the layer took 88 us, 68 of them stores)
+                __builtin_amdgcn_wave_barrier();   // the previous row's reads are done (same wave: LDS operations are in order)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const f32x4 v = acc[nn][m] + bv[half * 4 + nn];
+                    u16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(relu ? fmaxf(v[j], 0.f) : v[j]);
+                    *reinterpret_cast<u16x4 *>(oS + fc * kOPitch + nn * 32 + fk * 8) = o;
                 }
-        }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const size_t row_px = tile_px + (size_t)(wave * 4 + m) * Wo;
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {  // bias + ReLU + the one rounding
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + (half * 4 + nn) * 16 + fk * 4);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 v = acc[nn][m] + bv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) res[half][nn][m][j] = f2bf(relu ? fmaxf(v[j], 0.f) : v[j]);
+                for (int j = 0; j < 2; ++j) {
+                    const int pc = lane + 64 * j, px = pc >> 3, ch = pc & 7;
+                    const u16x8 v8 = *reinterpret_cast<const u16x8 *>(oS + px * kOPitch + ch * 16);
+                    const size_t off = (row_px + px) * kCout + half * 64 + ch * 8;
+                    if (!(OG_STEM_ABL & 1) || off == 12345) *reinterpret_cast<u16x8 *>(out + off) = v8;
+                }
             }
         }
-    }
-
-    // ---- bf16 tile through LDS (the operands are dead now), coalesced stores
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int px = (wave * 4 + m) * 16 + fc;
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
-                *reinterpret_cast<u16x4 *>(lds + px * kOPitch + ((half * 4 + nn) * 16 + fk * 4) * 2) = res[half][nn][m];
-        }
-    __syncthreads();
-    const size_t tile_px = ((size_t)n * Ho + ty * 16) * Wo + tx * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int g = tid + 256 * i, px = g >> 4, cg = g & 15;
-        const size_t off = (tile_px + (size_t)(px >> 4) * Wo + (px & 15)) * kCout + cg * 8;
-        if (!(OG_STEM_ABL & 1) || off == 12345)
-            *reinterpret_cast<u16x8 *>(out + off) = *reinterpret_cast<const u16x8 *>(lds + px * kOPitch + cg * 16);
+        __syncthreads();                       // everybody is done reading tile t's pixels
     }
 }
 
@@ -165,11 +180,14 @@ OG_API int OG_LP_NAME(og_stem7x7)(const float *images, const void *w_packed, con
                "%s: pointers must be 16-byte aligned", name);
     const long blocks = (long)N * (H / 32) * (W / 32);
     OG_REQUIRE(blocks < (1l << 31), OG_EINVAL, "%s: too many tiles", name);
-    constexpr int lds = kWBytes + kInBytes;
+    constexpr int lds = kWBytes + kInBytes + 4 * kOBytes;
     static OgAttrOnce attr;
     if (attr.need()) (void)hipFuncSetAttribute((const void *)stem7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, images,
-                       (const unsigned short *)w_packed, bias, (unsigned short *)out, H, W, relu);
+    // two workgroups per CU (LDS: 70.6 KB each), walking over the tiles
+    static const int per_launch = 2 * og_cu_count();
+    const unsigned grid = (unsigned)(blocks < per_launch ? blocks : per_launch);
+    hipLaunchKernelGGL(stem7x7_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, images,
+                       (const unsigned short *)w_packed, bias, (unsigned short *)out, H, W, relu, (int)blocks);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
