@@ -93,6 +93,13 @@ BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
 # submitted deepest level first, the order in which the trunk joins them on its way up.
 SIDE_SHARED = int(os.environ.get('OG_ENGINE_SIDE_SHARED', '0'))
 _shared_side = {}
+# OG_ENGINE_TRUNK_FIRST = D (0 = off): at the levels of depth >= D the up1 branch is queued on its side stream AFTER the first kernel
+# of the trunk below the fork point (it still depends on the fork point only, through an event recorded there).  The HIP graph
+# executor keeps a node on the queue of the parent whose FIRST child it is (capture order): with the branch captured first,
+# "fork point -> up1 -> merge" stays on one hardware queue and the latency-critical trunk is moved to a new one -- every merge
+# then waits across queues for the trunk (11 us in the forward timeline).  Trunk first: the trunk keeps its queue through forks
+# and merges, a fork costs it ~6 us instead (the release behind the fork point).
+TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
 CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
 BRANCH_MIN_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MIN_DEPTH', '0'))   # levels above this depth run up1 in the trunk, unforked
 _pending_branches = []
@@ -301,10 +308,13 @@ class _Residual:
                 self.w_cat = torch.cat([self.c2.w.permute(0, 2, 3, 1).reshape(cout, -1),
                                         self.skip.w.reshape(cout, -1)], 1).contiguous()
 
-    def __call__(self, x, merge_up=None):
+    def __call__(self, x, merge_up=None, after_c1=None):
         """-> the block's output; with `merge_up` (the up1 tensor of the hourglass level above, channels-last) and conv2 on
-        the tiled kernel: merge_up += nearest_x2(output) in conv2's epilogue, returns None (the output is never written)."""
+        the tiled kernel: merge_up += nearest_x2(output) in conv2's epilogue, returns None (the output is never written).
+        after_c1: called once the first kernel of the block has been launched (fork point of a side branch, _Level)."""
         y = self.c1(x)
+        if after_c1 is not None:
+            after_c1()
         n, c, h, w = y.shape
         if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS and not _WHATIF:
             return self._proj(y, x)
@@ -350,9 +360,10 @@ class _Level:
         self.low2 = (_Level(m.low2, dtype, fused, depth + 1) if isinstance(m.low2, HourglassLevel)
                      else _seq(m.low2, dtype, fused))
 
-    def _lower(self, x):
+    def _lower(self, x, after_first=None):
         """-> the input of low3's LAST residual (that one runs after the join: the merge may ride on its epilogue)"""
-        low = _run(self.low1, x)
+        low = self.low1[0](x, after_c1=after_first)
+        low = _run(self.low1[1:], low)
         low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
         return _run(self.low3[:-1], low)
 
@@ -370,9 +381,17 @@ class _Level:
                 else:
                     self._side = torch.cuda.Stream(x.device, priority=prio)
             box = {}
+            trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST and self.depth >= BRANCH_DELAY
+            fork_ev = None
+            if trunk_first:
+                fork_ev = torch.cuda.Event()
+                fork_ev.record(cur)                          # the fork point: x is complete here
 
             def start(side=self._side, depth=self.depth, box=box):
-                side.wait_stream(torch.cuda.current_stream(x.device))   # fork: up1 only needs x
+                if fork_ev is not None:
+                    side.wait_event(fork_ev)                 # fork: up1 only needs x
+                else:
+                    side.wait_stream(torch.cuda.current_stream(x.device))
                 outer = _issuer.branch
                 with torch.cuda.stream(side):
                     _issuer.branch = depth + 1
@@ -382,13 +401,19 @@ class _Level:
                         box['done'] = torch.cuda.Event()
                         box['done'].record(side)
 
+            after_first = None
             if self.depth < BRANCH_DELAY:
                 _pending_branches.append(start)               # started when the trunk enters depth BRANCH_DELAY
+            elif trunk_first:
+                def after_first():                            # called behind the first kernel of the trunk below
+                    while _pending_branches:
+                        _pending_branches.pop(-1 if SIDE_SHARED else 0)()
+                    start()
             else:
                 while _pending_branches:                      # (shared stream: deepest first = the order of the joins)
                     _pending_branches.pop(-1 if SIDE_SHARED else 0)()
                 start()
-            low = self._lower(x)
+            low = self._lower(x, after_first)
             while 'up' not in box:                            # (a delay deeper than the pyramid: start before the join)
                 _pending_branches.pop(0)()
             up = box['up']
