@@ -683,3 +683,17 @@ def test_engine_f16_matches_reference_golden(dev):
             err = np.abs(out[h][0][-1].cpu().numpy() - ref).max() / np.abs(ref).max()
             print(f'{name} fp16 (graph {use_graph}): relative error vs reference model {err:.2e}')
             assert err <= 4e-3, f'{name} fp16: relative error {err}'
+
+
+@pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"}])
+def test_engine_schedule_knobs(dev, knobs):
+    """The engine's kept A/B switches (read at import): merges as their own launches instead of on the producing convolution's
+    epilogue, up1 branch captured before the trunk below the fork -- the graph-engine tests again in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_engine_bench_shape_matches_eager or test_engine_other_shapes_match_eager or test_engine_matches_reference_golden"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
