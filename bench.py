@@ -6,7 +6,7 @@
                                                         one rank per GPU, no data-path collective)
 
 A step = one batch of 8 images (16 through the backbone with --flip) resident in HBM:
-bf16 channels-last backbone replayed as a HIP graph -> head outputs (+ synthetic GT-like
+fp16 (default; --dtype bf16) channels-last backbone replayed as a HIP graph -> head outputs (+ synthetic GT-like
 maps, see below) -> K1a bicubic x4 -> K1 NMS+top-k -> K2 limb collection -> K3 greedy grouping
 -> poses copied to pinned host memory.  Steps are software-pipelined one deep (the host picks
 up batch i-1's poses after queueing batch i); the grouping kernel and the pose copy run on a side stream.
@@ -60,14 +60,16 @@ def parse():
     ap.add_argument('--flip', action='store_true', help='flip-test (BASELINE config 3): 2x images through the backbone')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16',
-                    help='engine arithmetic: bf16 (default) or f16 (the reference evaluates in fp16 through apex O2); same MFMA rate')
+    ap.add_argument('--dtype', choices=['bf16', 'f16'], default='f16',
+                    help='engine arithmetic: f16 (default: the reference evaluates in fp16 through apex O2, evaluate.py:92,198-201) or '
+                         'bf16; same MFMA rate, fp16 is 8x closer to the fp32 module')
     ap.add_argument('--no-extras', action='store_true',
                     help='headline region only: skip the decoder-only / backbone-only / conv / HBM-cold / flip measurements')
     ap.add_argument('--allow-diagnostic', action='store_true',
                     help='run although a timing-only switch that produces WRONG RESULTS is set (OG_ENGINE_WHATIF, OG_DECODER_LIB, '
                          'OG_BENCH_FAIL_RANK): the JSON line then carries "diagnostic": true and is not a measurement')
-    ap.add_argument('--no-f16', action='store_true', help='skip the fp16-engine figure (the reference\'s apex-O2 arithmetic)')
+    ap.add_argument('--no-alt-dtype', '--no-f16', dest='no_alt_dtype', action='store_true',
+                    help='skip the figure for the other 16-bit arithmetic (bf16 beside the fp16 headline, or fp16 beside --dtype bf16)')
     ap.add_argument('--dry-run', action='store_true',
                     help='control plane only (CPU test aid): the ranks rendezvous over gloo, run the barrier / MAX-over-ranks '
                          'protocol and rank 0 prints the JSON skeleton with value null; no kernel runs')
@@ -332,20 +334,22 @@ def main():
         if a.size == 640:
             lib = _lib.load()
             cl = torch.channels_last
-            xs = [torch.randn(nb, 256, 160, 160, device=dev).to(torch.bfloat16).contiguous(memory_format=cl) for _ in range(3)]
-            wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(torch.bfloat16).contiguous(memory_format=cl)
+            lp_t = torch.float16 if a.dtype == 'f16' else torch.bfloat16
+            xs = [torch.randn(nb, 256, 160, 160, device=dev).to(lp_t).contiguous(memory_format=cl) for _ in range(3)]
+            wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(lp_t).contiguous(memory_format=cl)
             cb = torch.zeros(256, device=dev)
-            packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+            packed = torch.empty(wt.numel(), dtype=lp_t, device=dev)
+            conv_fn = _lib.lp(lib, 'og_conv3x3_tiled', lp_t)
             _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
 
             def conv_once(i):
-                _lib.check(lib.og_conv3x3_tiled_bf16(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
+                _lib.check(conv_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
                                                      _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
             timed(conv_once, 5)
             conv_us = timed(conv_once, 30) * 1e3
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
-                'kernel': 'C1 = og_conv3x3_tiled_bf16 (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
+                'kernel': 'C1 = og_conv3x3_tiled_' + a.dtype + ' (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
                           '256->256 layer, residual + bias + ReLU epilogue fused',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
                 'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
@@ -380,18 +384,19 @@ def main():
                                  'K0 flip merge, full decoder (BASELINE configs[2])'}
         del fpipe
 
-    # ---- the reference's arithmetic (fp16 through apex O2, evaluate.py:92,198-201) timed in the same process, same steps ----
-    f16_line = None
-    if not a.no_extras and not a.no_f16 and not a.flip and a.inflight == 1 and a.dtype != 'f16':
+    # ---- the other 16-bit arithmetic timed in the same process, same steps (headline fp16 = the reference's apex-O2 arithmetic,
+    # evaluate.py:92,198-201; the block beside it is the bf16 engine) ----
+    alt_line, alt_dtype = None, ('bf16' if a.dtype == 'f16' else 'f16')
+    if not a.no_extras and not a.no_alt_dtype and not a.flip and a.inflight == 1:
         torch.cuda.empty_cache()
-        hpipe = Pipeline(False, dtype='f16')
+        hpipe = Pipeline(False, dtype=alt_dtype)
         _, _, h_elapsed, h_stage = hpipe.timed_region(a.steps, a.warmup)
         h_bb = timed(lambda i: hpipe.engine.forward_raw(hpipe.images[i % n_rot]), 10)
-        f16_line = {'value': round(a.batch * a.steps * world / h_elapsed, 2), 'unit': 'images/sec',
+        alt_line = {'value': round(a.batch * a.steps * world / h_elapsed, 2), 'unit': 'images/sec',
                     'ms_per_step': round(h_elapsed / a.steps * 1e3, 3), 'backbone_ms_per_batch': round(h_bb, 3),
                     'k1_generate_limbs_us': round(float(np.mean(h_stage['k1_generate_limbs'])), 2),
-                    'workload': 'the headline workload with the fp16 engine (og_*_f16 kernels: same MFMA rate, 3 more mantissa '
-                                'bits; the reference evaluates in fp16)'}
+                    'workload': 'the headline workload with the %s engine (og_*_%s kernels: same MFMA rate; fp16 has 3 more mantissa '
+                                'bits and is what the reference evaluates in)' % (alt_dtype, alt_dtype)}
         del hpipe
 
     group = sharding.describe_group(dev)
@@ -436,8 +441,8 @@ def main():
         line.update(extras)
         if flip_line is not None:
             line['flip'] = flip_line
-        if f16_line is not None:
-            line['f16'] = f16_line
+        if alt_line is not None:
+            line[alt_dtype] = alt_line
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a, model, maps, cd)
         print(json.dumps(line))

@@ -268,6 +268,44 @@ int og_conv2d_proj_bf16(const void *x, const void *w_cat, const float *bias, con
                         int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2, int stride2, int relu,
                         void *workspace, size_t workspace_bytes, void *stream);
 size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int Cin2);
+/* ---- band-resident convolution for the SMALL levels (20x20 / 10x10 / 5x5 at batch 8): csrc/conv_band.hip.  A workgroup owns
+ * (image, band of output rows, 16 output channels) and all of K; K is split over its four waves (wave w = a quarter of the input
+ * channels, all nine taps), whose weight fragments go from the pre-packed image straight into registers; the band's input rows sit
+ * in LDS once (zero pixels between the rows: a tap is a plain address shift); the waves' fp32 partial tiles meet in LDS: no slabs,
+ * no tickets, nothing but finished activations is handed between workgroups.  Same arithmetic as og_conv2d_* / og_conv2d_proj_*
+ * (fp32 accumulation over the same products, one rounding; the summation ORDER differs, so results agree to fp32 rounding, not bit
+ * for bit).  Replaces convolution.forward models/hourglass_104.py:26-30 and residual.forward :70-79 (BN folded), stride 1 or 2,
+ * with the residual's 1x1 projection `skip` (:63-68) as extra K steps.
+ *   og_conv_band_supported: 0 = not served (needs 64 <= Cin (and Cin2) <= 512 in multiples of 32, Cout % 16 == 0, stride 1 | 2,
+ *     pad 1, input width <= 112, batch <= 64, a band's rows in 160 KiB of LDS); otherwise the number of workgroups of the launch.
+ *   og_conv_band_pack_w16: w (Cout,3,3,Cin) = the memory of a channels_last (Cout,Cin,3,3) tensor [+ w2 (Cout,Cin2), or NULL with
+ *     Cin2 = 0] -> packed, Cout * (9*Cin + Cin2) elements, once per layer.
+ *   og_conv_band_*: x (N,Hin,Win,Cin), skip / out (N,H,W,Cout) with H = (Hin-1)/stride + 1, x2 (N,H2,W2,Cin2) sampled at
+ *     (y*stride2, x*stride2) or NULL; bias fp32[Cout] (with a projection: the sum of both folded biases).
+ *   og_conv_band_chain_*: n_layers (<= 16) DEPENDENT layers in one launch -- layers[l].x must be layers[l-1].out; skip / x2 may be
+ *     the `out` of any earlier layer of the list or tensors complete before the launch; every `out` a distinct buffer; one batch
+ *     size.  Layer l+1's weight fetch, launch boundary and set-up hide behind layer l (the bottom of the hourglass is a chain of
+ *     ~5 us layers).  workspace: og_conv_band_chain_workspace_bytes() bytes, 128-byte aligned, ZERO before the first launch (the
+ *     launch leaves it zero); its last int is a sticky error word (non-zero: a bounded wait inside a launch ran out -- results of
+ *     that launch are invalid; never observed, kept so that a fault cannot hang the GPU).  Launches that share a workspace must be
+ *     stream-ordered. */
+typedef struct OgBandLayerDesc {
+    const void *x, *w_packed;
+    const float *bias;
+    const void *skip, *x2;
+    void *out;
+    int N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2;
+} OgBandLayerDesc;
+int og_conv_band_supported(int N, int Hin, int Win, int Cin, int Cout, int stride, int H2, int W2, int Cin2, int stride2);
+int og_conv_band_pack_w16(const void *w, const void *w2, int Cin, int Cout, int Cin2, void *packed, void *stream);
+size_t og_conv_band_chain_workspace_bytes(void);
+int og_conv_band_chain_supported(const OgBandLayerDesc *layers, int n_layers);   /* 1 = og_conv_band_chain_* serves the list as one launch */
+int og_conv_band_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, const void *x2, void *out, int N,
+                      int Hin, int Win, int Cin, int Cout, int stride, int relu, int H2, int W2, int Cin2, int stride2, void *stream);
+int og_conv_band_f16(const void *x, const void *w_packed, const float *bias, const void *skip, const void *x2, void *out, int N,
+                     int Hin, int Win, int Cin, int Cout, int stride, int relu, int H2, int W2, int Cin2, int stride2, void *stream);
+int og_conv_band_chain_bf16(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv_band_chain_f16(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
 /* ---- the same 3x3 stride-1 convolution for the LARGE levels (160x160 / 80x80 / 40x40 at 640x640 input), on weights tiled
  * once in advance: csrc/conv3x3_tiled.inc -- halo-tiled direct convolution, two 4-wave workgroups per CU, 32-channel K steps,
  * every weight stage one contiguous 8 KiB LDS image.  Same arithmetic and epilogue as og_conv3x3_bf16 (fp32 accumulation, the

@@ -61,6 +61,12 @@ SIGNATURES = {
     "og_conv2d_proj_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv2d_proj_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "og_conv3x3_debug_stamps": (None, [_vp]),
+    "og_conv_band_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "og_conv_band_pack_w16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "og_conv_band_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "og_conv_band_chain_workspace_bytes": (_sz, []),
+    "og_conv_band_chain_supported": (_i, [_vp, _i]),
+    "og_conv_band_chain_bf16": (_i, [_vp, _i, _vp, _sz, _vp]),
     "og_conv3x3_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
     "og_conv3x3_pack_w16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "og_conv3x3s2_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
@@ -83,6 +89,26 @@ for _name in [n for n in SIGNATURES if n.endswith('_bf16')]:
 SIGNATURES['og_nhwc_f16_to_nchw_f32'] = SIGNATURES['og_nhwc_bf16_to_nchw_f32']
 
 _lib = None
+
+
+class BandLayerDesc(C.Structure):
+    """OgBandLayerDesc (include/og_decoder.h): one layer of an og_conv_band_chain_* launch."""
+    _fields_ = [("x", _vp), ("w_packed", _vp), ("bias", _vp), ("skip", _vp), ("x2", _vp), ("out", _vp),
+                ("N", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Cout", _i), ("stride", _i), ("relu", _i),
+                ("H2", _i), ("W2", _i), ("Cin2", _i), ("stride2", _i)]
+
+
+def band_chain_supported(descs):
+    arr = (BandLayerDesc * len(descs))(*descs)
+    return bool(load().og_conv_band_chain_supported(arr, len(descs)))
+
+
+def band_chain(descs, dtype, workspace, device):
+    """og_conv_band_chain_*: `descs` = list of BandLayerDesc (layer l reads layer l-1's output), `workspace` = a zero-initialised
+    uint8 tensor of og_conv_band_chain_workspace_bytes() (one per set of stream-ordered launches)."""
+    lib = load()
+    arr = (BandLayerDesc * len(descs))(*descs)
+    check(lp(lib, 'og_conv_band_chain', dtype)(arr, len(descs), ptr(workspace), workspace.numel(), stream_ptr(device)), lib)
 
 
 def lp(lib, stem, dtype):

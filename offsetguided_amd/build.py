@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libog_decoder.so")
-SOURCES = ["abi.cpp", "nms_topk.hip", "upsample.hip", "collect.hip", "group.hip", "flip.hip", "epilogue.hip", "losses.hip", "conv3x3.hip", "encoder.hip", "stem.hip", "preprocess.hip"]
+SOURCES = ["abi.cpp", "nms_topk.hip", "upsample.hip", "collect.hip", "group.hip", "flip.hip", "epilogue.hip", "losses.hip", "conv3x3.hip", "conv_band.hip", "encoder.hip", "stem.hip", "preprocess.hip"]
 # the 16-bit-type specific files are compiled a second time for fp16 (csrc/lp_dtype.h)
-F16_SOURCES = ["conv3x3.hip", "epilogue.hip", "stem.hip"]
+F16_SOURCES = ["conv3x3.hip", "conv_band.hip", "epilogue.hip", "stem.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: every FMA in the kernels is explicit (bit-exact parity with torch-CPU fp32);
 # correctly-rounded fp32 divide/sqrt is hipcc's default and must stay on (no -ffast-math).

@@ -1,0 +1,822 @@
+// Band-resident 3x3 convolution (+ optional 1x1 projection along K) for the small hourglass levels: 20x20, 10x10 and 5x5 at
+// batch 8 (convolution.forward models/hourglass_104.py:26-30, residual.forward :70-79, the bottom of kp_module :183-190),
+// one layer per launch (og_conv_band_*) or a CHAIN of dependent layers in one launch (og_conv_band_chain_*).
+//
+// Why another kernel: those layers are GEMMs with M = 25 ... 400 pixels per image against K = 9*Cin = 3456 ... 4608.  The split-K
+// kernel of csrc/conv3x3.hip spends 61 % of a 13 us layer outside its K loop (set-up, fp32 slab publish, arrival ticket,
+// last-arriver gather: profiles/r03_o_chain_stamps.log).  Here nothing but finished activations is handed between workgroups:
+//   * a workgroup owns (image, band of output rows, 16 output channels) and ALL of K;
+//   * K is split over the WAVES of the workgroup: four waves (one per SIMD), wave w owns the 32-channel chunks kw*w .. kw*w+kw-1
+//     for all nine taps; its MFMA A operands -- 9 * kw fragments of 16 couts x 32 channels -- are 1-KiB contiguous pieces of a
+//     pre-packed weight image that go straight from global memory into its registers: one round trip, no LDS, no barrier;
+//   * the band's input rows (+ one above / below) sit in LDS once, [pixel][Cin] with a 32-byte pad per pixel, ONE ZERO PIXEL
+//     between consecutive rows and a zero row above / below the image: a tap is then a plain address shift for every lane (no
+//     validity select), and the 16 columns of an MFMA block are 16 CONSECUTIVE LDS pixels (the zero pixel between two rows is
+//     an output position whose result is dropped), so every ds_read_b128 is bank-conflict-free (slots 2p / 2p+1 mod 16; stride 2:
+//     16-byte pad, slots p / p+1).  Fragment reads run one step ahead of the MFMAs that consume them;
+//   * the four fp32 partial tiles meet in LDS (the staged input is dead by then), every output element is summed once and
+//     leaves through the fused bias / residual / ReLU epilogue as 8-byte stores (4 couts of one pixel per lane).
+// Work is XCD-aware: the workgroups that share a weight slice (same couts, different images / bands) run on one XCD, so a
+// slice crosses the fabric once per layer (speed only: no result depends on the placement).
+//
+// Chained form: a launch walks a list of layers, layer l reading what layer l-1 wrote.  Roles (layer, couts, image, band) are
+// handed out through per-(layer, XCD) ticket counters; a workgroup draws its ticket for layer l+1 while it works on layer l and
+// requests that role's weights as soon as its MFMAs of layer l have consumed the old ones; only then does it wait for the
+// per-image completion counter of layer l -- the weight fetch, the launch boundary and the set-up of a layer disappear behind
+// the layer before it.  Deadlock-free under ANY residency (no cooperative launch, other kernels may hold CUs): before a
+// workgroup waits for layer l it has seen every role of layer l taken, taking the untaken ones (of any XCD) itself; a role's
+// holder is running by construction, so the smallest unfinished layer always makes progress.  Hand-off as MI355X_MICROARCH.md
+// "inter-workgroup visibility", first measured row: write-through (sc1) stores, every storing wave's vmcnt(0), workgroup
+// barrier, ONE lane's agent-scope add; the consumer's single lane polls with sc1 loads, a workgroup barrier follows, every
+// load of handed-off bytes is an sc1 load to registers.  Every spin is bounded (a time-out raises the launch's error word
+// and goes on: wrong numbers, never a hang).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "lp_dtype.h"
+#include "og_common.h"
+
+namespace {
+
+typedef lp8 frag8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t kOob = 0x80000000u;   // per-lane buffer offset beyond any tensor this library accepts (< 2 GiB): reads as 0
+constexpr int kWaves = 4;                // one per SIMD
+constexpr int kMaxLayers = 16;           // layers of a chained launch (kernel arguments: 16 x 152 B)
+constexpr int kMaxImages = 64;
+constexpr int kSyncStride = 32;          // ints per counter: one 128-byte line each
+constexpr int kMaxLds = 160 * 1024 - 64; // LDS plan limit (the chained kernel keeps two words behind the plan's bytes)
+
+struct BandLayer {
+    const unsigned short *x;     // (N,Hin,Win,Cin)
+    const unsigned short *w;     // packed: [cout tile of 16][chunk of 32 channels][tap][lane][8], then the projection's [tile][chunk][lane][8]
+    const float *bias;           // fp32[Cout]
+    const unsigned short *skip;  // (N,H,W,Cout) or null
+    const unsigned short *x2;    // projection input (N,H2,W2,Cin2) or null
+    unsigned short *out;         // (N,H,W,Cout)
+    int N, Hin, Win, Cin, H, W, Cout, stride, relu;
+    int Cin2, H2, W2, stride2;
+    int bands, band_rows;        // output rows per band (the last band may be shorter)
+    int groups, total;           // groups = Cout / 16; total = groups * N * bands work items
+    int pitch, pitch2;           // LDS bytes per pixel of the x / x2 images
+    int x2_off, sb_off;          // LDS byte offsets of the x2 image and of the epilogue operands (residual slice + biases)
+    int w_bytes;
+    int kw, kw2;                 // 32-channel chunks per wave: ceil(Cin / 32 / 4), ceil(Cin2 / 32 / 4)
+    int in_chain;                // chained launch: bit 0 = x, bit 1 = skip, bit 2 = x2 was written by an earlier layer of THIS launch
+    uint32_t magic_p;            // ceil(2^32 / (Win + 1))
+};
+
+#ifdef OG_BAND_STAMPS   // tuning builds only (tools/build_variants.sh conv_band.hip stamps -DOG_BAND_STAMPS, tools/band_stamps.py)
+#define BAND_STAMP(i)                                                                                              \
+    do {                                                                                                           \
+        if (stamps && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime();                            \
+    } while (0)
+#else
+#define BAND_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+
+template <bool SC1>
+__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, SC1 ? 16 : 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+
+// This wave's K slice of cout tile g, straight to registers.  No branches around a wave's work: a chunk past the layer's
+// (Cin = 384 on the 16-chunk variant, Cin = 64 on any) loads through an out-of-range lane offset (zeros, no memory traffic)
+// and multiplies zeros -- uniform branches here made hipcc carry every accumulator through phi copies and spill.
+template <int KW, int KW2>
+__device__ __forceinline__ void band_load_weights(const BandLayer &a, int g, u32x4 (&wf)[KW][9], u32x4 (&wp)[KW2 > 0 ? KW2 : 1])
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nch = a.Cin >> 5, nch2 = a.Cin2 >> 5;
+    const __amdgpu_buffer_rsrc_t wr = rsrc_of(a.w, a.w_bytes);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int ch = wave * a.kw + k;
+        const uint32_t voff = (k < a.kw && ch < nch) ? (uint32_t)(lane << 4) : kOob;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wf[k][tap] = load16<false>(wr, voff, (uint32_t)(((g * nch + ch) * 9 + tap) << 10));
+    }
+    if (KW2 > 0) {
+        const uint32_t proj_base = (uint32_t)a.Cout * 9u * (uint32_t)a.Cin * 2u;
+#pragma unroll
+        for (int k = 0; k < KW2; ++k) {
+            const int ch = wave * a.kw2 + k;
+            const uint32_t voff = (a.x2 && k < a.kw2 && ch < nch2) ? (uint32_t)(lane << 4) : kOob;
+            wp[k] = load16<false>(wr, voff, proj_base + (uint32_t)((g * nch2 + ch) << 10));
+        }
+    }
+}
+
+#ifdef OG_BAND_STAMPS
+__device__ __forceinline__ int xcc_id_dbg() { return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 15u); }
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: behind a weight prefetch every barrier
+// would wait for ~40 KiB from HBM (3 us per layer of the chained form, measured).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    // simm16 = vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt(15) << 8 | vmcnt[5:4] << 14
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+// One role: layer `a`, cout tile g, work item (image, band), on a workgroup of EIGHT waves with fixed parts:
+//   waves 0-3, the COMPUTE waves (one per SIMD): hold the weight slices (requested by the caller: band_load_weights), run the
+//     MFMAs, exchange the partial tiles, run the epilogue and store; the only loads they ever issue are weights;
+//   waves 4-7, the LOADER waves: zero the border pixels, wait for the layer before (chained form), stage the input rows, the
+//     projection's pixels and the residual / bias operands of the epilogue into LDS; their first lane draws tickets and signals.
+// Why the split: vector memory operations of a wave retire in issue order.  A wave that has just requested 40 KiB of weights
+// for the NEXT layer cannot see a poll, a staged pixel or an epilogue operand of THIS layer before those have landed; with
+// the parts split, a prefetch only ever sits in front of the compute waves' own stores, and they order it behind them.
+// PT: 16-position column blocks per band (2, 4 or 7); KW / KW2: 32-channel chunks per compute wave of the 3x3 operand / of the
+// projection (compile-time upper bounds, a.kw / a.kw2 are the layer's); CHAIN: see the file header (wait_word / wait_target:
+// completion counter of the layer before, or null).  hook(1) runs (all threads) behind the barrier that precedes the MFMAs,
+// hook(2) / hook(3) in front of / behind the barrier that follows them; after_stores() runs behind the completion signal (the
+// chained kernel requests the next role's weights there).
+template <int PT, int KW, int KW2, bool CHAIN, typename F1, typename F2>
+__device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u32x4 (&wf)[KW][9], u32x4 (&wp)[KW2 > 0 ? KW2 : 1],
+                                          unsigned char *lds, const int *wait_word, int wait_target, int *done_word, int *error_word,
+                                          unsigned long long *stamps, F1 hook, F2 after_stores)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool cw = wave < kWaves;                 // compute wave (else loader wave)
+    const int ltid = tid - kWaves * 64;            // loader thread 0 .. 255
+    const int lwave = wave - kWaves;
+    const int nch = a.Cin >> 5, nch2 = a.Cin2 >> 5;
+    const int img = item / a.bands, band = item - img * a.bands;
+    const int y0 = band * a.band_rows, rows = min(a.band_rows, a.H - y0);
+    const int P = a.Win + 1;                       // LDS pixels per image row: the row + one zero pixel
+    const int NR = (rows - 1) * a.stride + 3;      // LDS rows: input rows y0*stride-1 .. (y0+rows-1)*stride+1 (zeros outside the image)
+    const int ri0 = y0 * a.stride - 1;
+    const int Q = rows * P - 1;                    // output positions of the band (the zero pixels between rows included)
+    const bool x_chain = CHAIN && (a.in_chain & 1), skip_chain = CHAIN && (a.in_chain & 2), x2_chain = CHAIN && (a.in_chain & 4);
+    const bool has_proj = KW2 > 0 && a.x2 != nullptr;
+#ifdef OG_BAND_STAMPS
+#define LSTAMP(i) do { if (stamps && tid == kWaves * 64) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMP(i) do { if (stamps && tid == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#define CSTAMP(i) do { } while (0)
+#endif
+    LSTAMP(0);
+
+    if (!cw) {
+        // ---- zero pixels of the LDS image: the leading pixel, the pixel behind every row, the rows outside the image
+        const int slots = a.pitch >> 4;            // 16-byte slots per pixel
+        for (int s = ltid; s < (NR + 1) * slots; s += kWaves * 64) {
+            const int i = s / slots, sl = s - i * slots;
+            const int px = i == 0 ? 0 : 1 + (i - 1) * P + a.Win;
+            *reinterpret_cast<u32x4 *>(lds + px * a.pitch + (sl << 4)) = (u32x4){0, 0, 0, 0};
+        }
+        if (ri0 < 0)
+            for (int s = ltid; s < a.Win * slots; s += kWaves * 64) *reinterpret_cast<u32x4 *>(lds + a.pitch + (s << 4)) = (u32x4){0, 0, 0, 0};
+        if (ri0 + NR - 1 >= a.Hin)
+            for (int s = ltid; s < a.Win * slots; s += kWaves * 64)
+                *reinterpret_cast<u32x4 *>(lds + (1 + (NR - 1) * P) * a.pitch + (s << 4)) = (u32x4){0, 0, 0, 0};
+        // ---- chained form: the layer before must be complete for this image (one lane polls, bounded; the barrier below
+        // brings the news to the other waves)
+        if (CHAIN && wait_word && ltid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {
+                    __hip_atomic_store(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    // (All eight waves meet here.  Letting only the loader waves meet -- through an LDS word, the compute waves still issuing
+    // their weight prefetch -- was measured: 30 us per layer instead of 7.5; the two streams of loads then interleave in the
+    // CU's one vector memory pipe, EXPERIMENTS.md)
+    if (CHAIN && wait_word) lds_barrier();
+    LSTAMP(1);
+
+    if (!cw) {
+        // ---- activations: whole pixels, one per wave instruction (Cin / 8 <= 64 lanes x 16 B), into the padded LDS image
+        {
+            const int r_lo = max(ri0, 0), r_hi = min(ri0 + NR - 1, a.Hin - 1);      // input rows that exist
+            const int npix = (r_hi - r_lo + 1) * a.Win;
+            const unsigned short *src = a.x + (size_t)(img * a.Hin + r_lo) * a.Win * a.Cin;
+            const __amdgpu_buffer_rsrc_t xr = rsrc_of(src, npix * a.Cin * 2);
+            const bool lane_on = lane < (a.Cin >> 3);
+            const uint32_t magic_w = a.Win <= 1 ? 0u : (uint32_t)(((1ull << 32) + a.Win - 1) / a.Win);
+            constexpr int SB = 8;
+            for (int p0 = lwave; p0 < npix; p0 += SB * kWaves) {
+                u32x4 v[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int p = p0 + i * kWaves;
+                    const uint32_t vo = (lane_on && p < npix) ? (uint32_t)((lane << 4) + p * a.Cin * 2) : kOob;
+                    v[i] = x_chain ? load16<true>(xr, vo, 0) : load16<false>(xr, vo, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int p = p0 + i * kWaves;
+                    const int r = magic_w ? (int)__umulhi((uint32_t)p, magic_w) : p, c = p - r * a.Win;
+                    const int px = 1 + (r_lo - ri0 + r) * P + c;
+                    if (lane_on && p < npix) *reinterpret_cast<u32x4 *>(lds + px * a.pitch + (lane << 4)) = v[i];
+                }
+            }
+        }
+        if (has_proj) {   // the projection reads the block input at (y * stride2, x * stride2): staged dense by output position
+            const __amdgpu_buffer_rsrc_t x2r = rsrc_of(a.x2, a.N * a.H2 * a.W2 * a.Cin2 * 2);
+            const bool lane_on = lane < (a.Cin2 >> 3);
+            constexpr int SB = 8;
+            for (int q0 = lwave; q0 < Q; q0 += SB * kWaves) {
+                u32x4 v[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int q = q0 + i * kWaves;
+                    const int y = (int)div_magic((uint32_t)q, a.magic_p), x = q - y * P;
+                    const bool ok = lane_on && q < Q && x < a.W;
+                    const uint32_t vo = ok ? (uint32_t)(((((img * a.H2 + (y0 + y) * a.stride2) * a.W2 + x * a.stride2) * a.Cin2) << 1) + (lane << 4)) : kOob;
+                    v[i] = x2_chain ? load16<true>(x2r, vo, 0) : load16<false>(x2r, vo, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int q = q0 + i * kWaves;
+                    if (lane_on && q < Q) *reinterpret_cast<u32x4 *>(lds + a.x2_off + q * a.pitch2 + (lane << 4)) = v[i];
+                }
+            }
+        }
+        // ---- epilogue operands: [position][16 couts] of the residual (32 B each), then the tile's 16 biases (64 B)
+        {
+            const __amdgpu_buffer_rsrc_t sr = rsrc_of(a.skip, a.skip ? a.N * a.H * a.W * a.Cout * 2 : 0);
+            for (int s = ltid; s < PT * 32; s += kWaves * 64) {      // 16-byte piece s: position s / 2, couts 8 * (s & 1) ..
+                const int q = s >> 1;
+                const int y = (int)div_magic((uint32_t)q, a.magic_p), x = q - y * P;
+                const bool ok = a.skip && q < Q && x < a.W;
+                const uint32_t vo = ok ? (uint32_t)(((((img * a.H + y0 + y) * a.W + x) * a.Cout + g * 16 + (s & 1) * 8)) << 1) : kOob;
+                const u32x4 v = skip_chain ? load16<true>(sr, vo, 0) : load16<false>(sr, vo, 0);
+                *reinterpret_cast<u32x4 *>(lds + a.sb_off + (s << 4)) = v;
+            }
+            if (ltid < 4) *reinterpret_cast<f32x4 *>(lds + a.sb_off + PT * 512 + (ltid << 4)) = *reinterpret_cast<const f32x4 *>(a.bias + g * 16 + ltid * 4);
+        }
+    }
+    LSTAMP(2);
+    lds_barrier();
+    hook(1);             // (loader waves are idle from here to the end of the role)
+
+    // ---- MFMA: position q = 16 t + column reads LDS pixel 1 + P + stride*q + (dy*P + dx).  Fragment reads run D steps ahead of
+    // the MFMAs that consume them (sched_barrier: left alone, hipcc sinks every read in front of its MFMA -- one read in flight,
+    // 37 cycles per MFMA instead of 16 -- and recomputes the 64-bit address products per read)
+    const int col = lane & 15, fk = lane >> 4;
+    f32x4 acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (cw) {
+        constexpr int D = PT >= 7 ? 1 : PT == 4 ? 2 : 3, NB = D + 1, NS = KW * 9;
+        int base[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            base[t] = (1 + P + a.stride * (t * 16 + col)) * a.pitch + (fk << 4);
+            asm volatile("" : "+v"(base[t]));          // a register, not a recipe
+        }
+        auto step_off = [&](int s) {     // s = k * 9 + tap; a chunk past the layer's multiplies zero weights: any in-range chunk does
+            const int k = s / 9, tap = s - k * 9;
+            const int ch = min(wave * a.kw + min(k, a.kw - 1), nch - 1);
+            return ((tap / 3 - 1) * P + (tap % 3 - 1)) * a.pitch + (ch << 6);
+        };
+        frag8 b[NB][PT];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int off = step_off(s);
+#pragma unroll
+            for (int t = 0; t < PT; ++t) b[s % NB][t] = *reinterpret_cast<const frag8 *>(lds + base[t] + off);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + D < NS) {
+                const int off = step_off(s + D);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) b[(s + D) % NB][t] = *reinterpret_cast<const frag8 *>(lds + base[t] + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[t] = OG_LP_MFMA(__builtin_bit_cast(frag8, wf[s / 9][s % 9]), b[s % NB][t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (has_proj) {
+#pragma unroll
+            for (int k = 0; k < (KW2 > 0 ? KW2 : 1); ++k) {
+                const int ch = min(wave * a.kw2 + min(k, a.kw2 - 1), nch2 - 1);
+                frag8 bp[PT];
+#pragma unroll
+                for (int t = 0; t < PT; ++t) bp[t] = *reinterpret_cast<const frag8 *>(lds + a.x2_off + (t * 16 + col) * a.pitch2 + (ch << 6) + (fk << 4));
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t] = OG_LP_MFMA(__builtin_bit_cast(frag8, wp[k]), bp[t], acc[t]);
+            }
+        }
+    }
+    CSTAMP(3);
+
+    // ---- the four partial tiles meet in LDS: [wave][t][lane] float4 over the (dead) staged input
+    hook(2);
+    lds_barrier();
+    hook(3);
+    if (cw) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) *reinterpret_cast<f32x4 *>(lds + (((wave * PT + t) << 6) + lane) * 16) = acc[t];
+    }
+    lds_barrier();
+    CSTAMP(4);
+    if (cw) {
+        // epilogue: thread o owns 4 couts of one output position (PT = 7: 448 owners on 256 threads)
+        const __amdgpu_buffer_rsrc_t orr = rsrc_of(a.out, a.N * a.H * a.W * a.Cout * 2);
+#pragma unroll
+        for (int rep = 0; rep < (PT > 4 ? 2 : 1); ++rep) {
+            const int o = tid + rep * kWaves * 64, l = o & 63, t = o >> 6;
+            const int q = t * 16 + (l & 15);
+            const int y = (int)div_magic((uint32_t)q, a.magic_p), x = q - y * P;
+            if (o < PT * 64 && q < Q && x < a.W) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(lds + a.sb_off + PT * 512 + ((l >> 4) << 4));
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) v += *reinterpret_cast<const f32x4 *>(lds + (((w * PT + t) << 6) + l) * 16);
+                const u32x2 sk = *reinterpret_cast<const u32x2 *>(lds + a.sb_off + (q << 5) + ((l >> 4) << 3));
+                v[0] += lp2f((unsigned short)(sk[0] & 0xffffu));
+                v[1] += lp2f((unsigned short)(sk[0] >> 16));
+                v[2] += lp2f((unsigned short)(sk[1] & 0xffffu));
+                v[3] += lp2f((unsigned short)(sk[1] >> 16));
+                if (a.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                u32x2 ov;
+                ov[0] = (uint32_t)f2lp(v[0]) | ((uint32_t)f2lp(v[1]) << 16);
+                ov[1] = (uint32_t)f2lp(v[2]) | ((uint32_t)f2lp(v[3]) << 16);
+                const size_t oidx = ((size_t)(img * a.H + y0 + y) * a.W + x) * a.Cout + g * 16 + (l >> 4) * 4;
+                if (CHAIN) __builtin_amdgcn_raw_buffer_store_b64(ov, orr, (uint32_t)(oidx << 1), 0, 16);     // write-through
+                else *reinterpret_cast<u32x2 *>(a.out + oidx) = ov;
+            }
+        }
+    }
+    CSTAMP(5);
+    if (CHAIN) {
+        // every storing wave drains its write-through stores, the workgroup meets, ONE lane signals
+        wait_vmcnt<0>();
+        lds_barrier();            // (also: every wave is done reading the partial tiles -- the next role may write the LDS)
+        if (ltid == 0 && done_word) __hip_atomic_fetch_add(done_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LSTAMP(6);
+        // The next role's weights are requested only now: issued in front of the drain (younger than the stores, counted
+        // vmcnt) they delayed the stores' acknowledgements by the whole fetch (2.7 us per layer: the write-through stores and
+        // 37 MB of weight reads share the path to the memory side); behind the signal they still have the poll, the staging
+        // and the barriers of the next role (4 us) to land
+        after_stores();
+    } else {
+        (void)after_stores;
+#ifdef OG_BAND_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CSTAMP(6);
+#endif
+    }
+#undef LSTAMP
+#undef CSTAMP
+}
+
+template <int PT, int KW, int KW2>
+__global__ void __launch_bounds__(2 * kWaves * 64)
+conv_band_kernel(BandLayer a, unsigned long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int wid = og_xcd_remap(blockIdx.x, gridDim.x);   // grid: a multiple of 8; consecutive work ids share an XCD
+    if (wid >= a.total) return;
+    const int items = a.N * a.bands;
+    const int g = wid / items;
+    u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
+    if (threadIdx.x < kWaves * 64) band_load_weights<KW, KW2>(a, g, wf, wp);
+    band_role<PT, KW, KW2, false>(a, g, wid - g * items, wf, wp, lds, nullptr, 0, nullptr, nullptr,
+                                  stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr, [](int) {}, [] {});
+}
+
+struct ChainArgs {
+    BandLayer layer[kMaxLayers];
+    int n_layers;
+    int word_off;       // LDS byte offset of the kernel's four broadcast words (behind every layer's plan)
+    int *sync;          // [tickets: kMaxLayers x 8][done: kMaxLayers x kMaxImages][exited][error], kSyncStride ints each
+};
+
+__device__ __forceinline__ int xcc_id()
+{
+    return (int)(__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
+}
+
+// Roles of XCD x in layer `a`: the cout tiles g = x, x + 8, ... times every work item; ticket t -> (g = x + 8 * (t / items), item)
+__device__ __forceinline__ int xcd_roles(const BandLayer &a, int x) { return ((a.groups - x + 7) >> 3) * a.N * a.bands; }
+
+template <int PT, int KW, int KW2>
+__global__ void __launch_bounds__(2 * kWaves * 64)
+conv_band_chain_kernel(ChainArgs c, unsigned long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    int *const s_word = reinterpret_cast<int *>(lds + c.word_off);   // (static LDS beside 1024-aligned dynamic LDS would cost 1 KiB)
+    const int tid = threadIdx.x;
+    const bool cw = tid < kWaves * 64;             // compute wave; thread kWaves * 64 (first loader lane) is the control thread
+    const bool ctl = tid == kWaves * 64;
+    const int L = c.n_layers;
+    int *const tickets = c.sync, *const done = c.sync + kMaxLayers * 8 * kSyncStride;
+    int *const exited = done + kMaxLayers * kMaxImages * kSyncStride, *const error = exited + kSyncStride;
+    const int x = xcc_id();
+    u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
+    auto take = [&](int l, int xx) {       // every thread gets the ticket the control thread drew
+        if (ctl) s_word[0] = __hip_atomic_fetch_add(tickets + (l * 8 + xx) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_barrier();
+        const int t = s_word[0];
+        lds_barrier();
+        return t;
+    };
+    auto role_g = [&](int l, int xx, int t) { return xx + 8 * (t / (c.layer[l].N * c.layer[l].bands)); };
+    auto wait_of = [&](int l, int img) { return l > 0 ? done + ((l - 1) * kMaxImages + img) * kSyncStride : (int *)nullptr; };
+    auto stamp_of = [&](int l, int xx, int t) { return stamps ? stamps + ((size_t)l * 4096 + (size_t)(xx * 512 + (t & 511))) * 8 : (unsigned long long *)nullptr; };
+
+    // Every layer's descriptor (three 64-byte lines of kernel arguments each, in device memory) is pulled into the scalar cache
+    // NOW, all requests in flight together: first touched at the top of its layer, the misses cost every workgroup ~2 us per
+    // layer (measured: every role entered 3 us behind its predecessor's signal)
+    {
+        int acc = 0;
+        const int *tab = reinterpret_cast<const int *>(&c.layer[0]);
+        for (int i = 0; i < L * (int)(sizeof(BandLayer) / 4); i += 16) acc ^= tab[i];
+        asm volatile("" ::"s"(acc));
+    }
+    // Tickets run TWO layers ahead: the draw for layer l+2 (and the look at layer l+1's counters, see below) is issued by the
+    // control thread while the compute waves run layer l's MFMAs -- the loader waves have nothing to do then -- and is read one
+    // role later.  Issued at the top of a role instead, the returning atomic was still in flight when the role's address
+    // arithmetic reused its destination register, and hipcc's guard (s_waitcnt vmcnt(0)) stalled the control wave for the
+    // atomic's round trip: 3-4 us per layer, every role entered that much behind its predecessor's signal.
+    int t_cur = take(0, x);
+    int t_next = L > 1 ? take(1, x) : 0x7fffffff;
+    bool open_cur = true, have_w = false;      // open_cur: layer l may still have roles nobody took (layer 0: unknown)
+    const bool peeker = tid >= kWaves * 64 && tid < kWaves * 64 + 8;
+    for (int l = 0; l < L; ++l) {
+        const BandLayer &a = c.layer[l];
+        int t_draw = 0x7fffffff, peek = 0x7fffffff, t_next2 = 0x7fffffff;
+        bool open_next = true;
+        auto hook = [&](int point) {
+            if (point == 1) {                 // the MFMAs start: draw for layer l+2, look at layer l+1's counters
+                if (l + 2 < L && ctl)
+                    t_draw = __hip_atomic_fetch_add(tickets + ((l + 2) * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l + 1 < L && peeker)
+                    peek = __hip_atomic_load(tickets + ((l + 1) * 8 + ((x + tid) & 7)) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (point == 2) {          // every wave retires them here (pending on some path, hipcc guards the first reuse
+                asm volatile("" ::"v"(t_draw), "v"(peek));     // of their registers with a vmcnt(0)); the control wave publishes
+                if (tid >= kWaves * 64 && tid < kWaves * 64 + 64) {
+                    const unsigned long long m = __ballot(l + 1 < L && peeker && peek < xcd_roles(c.layer[l + 1 < L ? l + 1 : l], (x + tid) & 7));
+                    if (ctl) { s_word[0] = t_draw; s_word[1] = m != 0; }
+                }
+            } else if (point == 3) {
+                t_next2 = s_word[0];
+                open_next = s_word[1] != 0;
+            }
+        };
+        if (t_cur < xcd_roles(a, x)) {
+            const int items = a.N * a.bands, g = role_g(l, x, t_cur), item = t_cur % items, img = item / a.bands;
+            if (!have_w && cw) band_load_weights<KW, KW2>(a, g, wf, wp);
+            have_w = false;
+            band_role<PT, KW, KW2, true>(
+                a, g, item, wf, wp, lds, wait_of(l, img), l > 0 ? c.layer[l - 1].groups * c.layer[l - 1].bands : 0,
+                done + (l * kMaxImages + img) * kSyncStride, error, stamp_of(l, x, t_cur), hook,
+                [&] {
+                    if (l + 1 < L && t_next < xcd_roles(c.layer[l + 1], x)) {
+                        if (cw) band_load_weights<KW, KW2>(c.layer[l + 1], role_g(l + 1, x, t_next), wf, wp);
+                        have_w = true;
+                    }
+                });
+        } else {
+            hook(1);
+            hook(2);
+            lds_barrier();
+            hook(3);
+            lds_barrier();
+        }
+        // Before anybody here may wait for layer l to complete, every role of layer l must have a (running) holder: take what
+        // is left in any XCD's queue (workgroups that are not resident).  One wave instruction looks at the eight counters.  In
+        // the common case the look during layer l-1 has already found every role of layer l taken.
+        while (open_cur) {
+            if (tid >= kWaves * 64 && tid < kWaves * 64 + 64) {
+                const int i = tid - kWaves * 64, xx = (x + i) & 7;
+                const bool open = i < 8 &&
+                                  __hip_atomic_load(tickets + (l * 8 + xx) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < xcd_roles(a, xx);
+                const unsigned long long m = __ballot(open);
+                if (ctl) s_word[1] = m ? ((x + __builtin_ctzll(m)) & 7) : -1;
+            }
+            lds_barrier();
+            const int xx = s_word[1];
+            lds_barrier();
+            if (xx < 0) break;
+            const int t = take(l, xx);
+            if (t < xcd_roles(a, xx)) {
+                const int items = a.N * a.bands, item = t % items, img = item / a.bands;
+                if (cw) band_load_weights<KW, KW2>(a, role_g(l, xx, t), wf, wp);       // (this overwrites a prefetched slice: reloaded below)
+                have_w = false;
+                band_role<PT, KW, KW2, true>(a, role_g(l, xx, t), item, wf, wp, lds, wait_of(l, img),
+                                             l > 0 ? c.layer[l - 1].groups * c.layer[l - 1].bands : 0,
+                                             done + (l * kMaxImages + img) * kSyncStride, error, stamp_of(l, xx, t), [](int) {}, [] {});
+            }
+        }
+        t_cur = t_next;
+        t_next = t_next2;
+        open_cur = open_next;
+    }
+    // the last workgroup out clears the launch's words for the next launch (everybody else has stopped touching them)
+    if (ctl) {
+        const int n = __hip_atomic_fetch_add(exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == (int)gridDim.x - 1) {
+            for (int l = 0; l < L; ++l) {
+                for (int xx = 0; xx < 8; ++xx) __hip_atomic_store(tickets + (l * 8 + xx) * kSyncStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < c.layer[l].N; ++i) __hip_atomic_store(done + (l * kMaxImages + i) * kSyncStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// OHWI weights (the memory order of a channels_last (Cout,Cin,3,3) tensor) [+ the projection's (Cout,Cin2)] -> fragment order:
+// every (cout tile, chunk, tap) is the 1-KiB register image of one wave-wide 16-byte load (lane = cout row + 16 * k octet).
+__global__ void __launch_bounds__(256)
+conv_band_pack_kernel(const unsigned short *w, const unsigned short *w2, unsigned short *packed, int Cin, int Cout, int Cin2)
+{
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    const long main_slots = (long)Cout * 9 * Cin / 8, proj_slots = (long)Cout * Cin2 / 8;
+    if (slot >= main_slots + proj_slots) return;
+    const unsigned short *src;
+    if (slot < main_slots) {
+        const int lane = (int)(slot & 63);
+        long rest = slot >> 6;
+        const int tap = (int)(rest % 9);
+        rest /= 9;
+        const int nch = Cin >> 5, chunk = (int)(rest % nch), g = (int)(rest / nch);
+        src = w + ((size_t)(g * 16 + (lane & 15)) * 9 + tap) * Cin + chunk * 32 + (lane >> 4) * 8;
+    } else {
+        const long s2 = slot - main_slots;
+        const int lane = (int)(s2 & 63);
+        const long rest = s2 >> 6;
+        const int nch2 = Cin2 >> 5, chunk = (int)(rest % nch2), g = (int)(rest / nch2);
+        src = w2 + (size_t)(g * 16 + (lane & 15)) * Cin2 + chunk * 32 + (lane >> 4) * 8;
+    }
+    *reinterpret_cast<u32x4 *>(packed + slot * 8) = *reinterpret_cast<const u32x4 *>(src);
+}
+
+struct BandPlan {
+    int pt, lds_bytes, grid;
+};
+
+// LDS bytes of layer `a` on a kernel with pt column blocks (sets a.x2_off, a.sb_off)
+int band_lds(BandLayer &a, int pt)
+{
+    const int P = a.Win + 1, NR = (a.band_rows - 1) * a.stride + 3;
+    // fragment reads of the dropped positions of the last column block reach past the image: the allocation covers them
+    const int reach = 1 + P + a.stride * (pt * 16 - 1) + P + 2;
+    const int img_px = (1 + NR * P) > reach ? (1 + NR * P) : reach;
+    a.x2_off = (img_px * a.pitch + 15) & ~15;
+    const int staged = a.x2_off + pt * 16 * a.pitch2;
+    // the epilogue operands sit behind the staged images AND behind the partial tiles that overlay them
+    a.sb_off = staged > kWaves * pt * 1024 ? staged : kWaves * pt * 1024;
+    return a.sb_off + pt * 512 + 64;
+}
+
+// Fills the geometry fields of `a` (shapes must be set) and picks the kernel variant; false = this layer is not served.
+bool band_plan(BandLayer &a, BandPlan &p)
+{
+    if (a.Cin % 32 || a.Cin < 64 || a.Cin > 512 || a.Cout % 16 || a.Cout <= 0) return false;
+    if (a.stride != 1 && a.stride != 2) return false;
+    if (a.x2 && (a.Cin2 % 32 || a.Cin2 < 64 || a.Cin2 > 512 || (a.stride2 != 1 && a.stride2 != 2))) return false;
+    if (!a.x2) a.Cin2 = 0;
+    if (a.N > kMaxImages) return false;
+    a.H = (a.Hin - 1) / a.stride + 1;
+    a.W = (a.Win - 1) / a.stride + 1;
+    if (a.H <= 0 || a.W <= 0 || a.Win + 1 > 113) return false;
+    if (a.x2 && ((a.H2 - 1) / a.stride2 + 1 != a.H || (a.W2 - 1) / a.stride2 + 1 != a.W)) return false;
+    if ((long)a.N * a.Hin * a.Win * a.Cin >= (1l << 30) || (long)a.N * a.H * a.W * a.Cout >= (1l << 30)) return false;
+    if (a.x2 && (long)a.N * a.H2 * a.W2 * a.Cin2 >= (1l << 30)) return false;
+    a.kw = (a.Cin / 32 + kWaves - 1) / kWaves;
+    a.kw2 = (a.Cin2 / 32 + kWaves - 1) / kWaves;
+    a.pitch = a.Cin * 2 + (a.stride == 1 ? 32 : 16);
+    a.pitch2 = a.x2 ? a.Cin2 * 2 + 32 : 0;
+    const int P = a.Win + 1;
+    // the tallest band of at most 112 output positions (7 MFMA column blocks) whose LDS image fits
+    int rows = a.H < 113 / P ? a.H : 113 / P;
+    for (; rows >= 1; --rows) {
+        const int bands = (a.H + rows - 1) / rows, r = (a.H + bands - 1) / bands;   // balanced
+        const int Q = r * P - 1, pt = Q <= 32 ? 2 : Q <= 64 ? 4 : 7;
+        if (Q > 112) continue;
+        a.bands = bands; a.band_rows = r;
+        const int lds = band_lds(a, pt);
+        if (lds <= kMaxLds) {
+            p.pt = pt; p.lds_bytes = lds;
+            break;
+        }
+    }
+    if (rows < 1) return false;
+    a.groups = a.Cout / 16;
+    a.total = a.groups * a.N * a.bands;
+    a.w_bytes = a.Cout * (9 * a.Cin + a.Cin2) * 2;
+    a.magic_p = (uint32_t)(((1ull << 32) + P - 1) / P);
+    p.grid = (a.total + 7) / 8 * 8;
+    return true;
+}
+
+#ifdef OG_BAND_STAMPS
+unsigned long long *g_band_stamps = nullptr;
+int g_band_launch = 0;
+#endif
+
+int fill_layer(const char *name, BandLayer &a, BandPlan &p, const OgBandLayerDesc &d)
+{
+    OG_REQUIRE(d.x && d.w_packed && d.bias && d.out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(d.N > 0 && d.Hin > 0 && d.Win > 0, OG_EINVAL, "%s: bad shape", name);
+    a = BandLayer{};
+    a.x = (const unsigned short *)d.x; a.w = (const unsigned short *)d.w_packed; a.bias = d.bias; a.skip = (const unsigned short *)d.skip;
+    a.x2 = (const unsigned short *)d.x2; a.out = (unsigned short *)d.out;
+    a.N = d.N; a.Hin = d.Hin; a.Win = d.Win; a.Cin = d.Cin; a.Cout = d.Cout; a.stride = d.stride; a.relu = d.relu;
+    a.H2 = d.H2; a.W2 = d.W2; a.Cin2 = d.x2 ? d.Cin2 : 0; a.stride2 = d.stride2;
+    OG_REQUIRE(band_plan(a, p), OG_EUNSUPPORTED,
+               "%s: not served (needs 64 <= Cin <= 512 in multiples of 32, Cout %% 16 == 0, stride 1|2, input width <= 112, batch <= 64, the "
+               "band in 160 KiB of LDS; got %dx%d, %d -> %d, stride %d, projection %d)", name, d.Hin, d.Win, d.Cin, d.Cout, d.stride, a.Cin2);
+    return OG_OK;
+}
+
+}  // namespace
+
+#ifndef OG_DT_F16
+#ifdef OG_BAND_STAMPS
+// buf: [launches][4096 workgroups][8] u64; every og_conv_band_* call after this fills the next [4096][8] block (a chained
+// launch: one block per layer, role (xcd, ticket) at xcd * 512 + ticket)
+OG_API void og_conv_band_debug_stamps(void *buf) { g_band_stamps = (unsigned long long *)buf; g_band_launch = 0; }
+#endif
+
+OG_API int og_conv_band_supported(int N, int Hin, int Win, int Cin, int Cout, int stride, int H2, int W2, int Cin2, int stride2)
+{
+    if (N <= 0 || Hin <= 0 || Win <= 0) return 0;
+    BandLayer a = {};
+    BandPlan p;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.stride = stride;
+    if (Cin2 > 0) { a.x2 = (const unsigned short *)16; a.H2 = H2; a.W2 = W2; a.Cin2 = Cin2; a.stride2 = stride2; }
+    if (!band_plan(a, p)) return 0;
+    return a.total;
+}
+
+OG_API size_t og_conv_band_chain_workspace_bytes(void)
+{
+    return (size_t)(kMaxLayers * 8 + kMaxLayers * kMaxImages + 2) * kSyncStride * sizeof(int);
+}
+
+OG_API int og_conv_band_pack_w16(const void *w, const void *w2, int Cin, int Cout, int Cin2, void *packed, void *stream)
+{
+    OG_REQUIRE(w && packed && (Cin2 == 0 || w2), OG_EINVAL, "og_conv_band_pack_w16: null pointer");
+    OG_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 16 == 0 && Cin2 >= 0 && Cin2 % 32 == 0, OG_EUNSUPPORTED,
+               "og_conv_band_pack_w16: Cin, Cin2 must be multiples of 32 and Cout of 16 (got %d + %d -> %d)", Cin, Cin2, Cout);
+    const long slots = (long)Cout * (9 * Cin + Cin2) / 8;
+    hipLaunchKernelGGL(conv_band_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)w, (const unsigned short *)w2, (unsigned short *)packed, Cin, Cout, Cin2);
+    OG_LAUNCH_CHECK("og_conv_band_pack_w16");
+    return OG_OK;
+}
+#endif
+
+// kernel variants: PT (column blocks) x chunks per wave (3 = Cin <= 384, 4 = Cin <= 512) x projection chunks per wave (0 / 4)
+#define BAND_DISPATCH(KERNEL, pt_, kw_, kw2_)                                                                  \
+    do {                                                                                                      \
+        if (pt_ == 2) { if (kw_ <= 3) { if (kw2_) KERNEL(2, 3, 4); else KERNEL(2, 3, 0); }                    \
+                        else { if (kw2_) KERNEL(2, 4, 4); else KERNEL(2, 4, 0); } }                           \
+        else if (pt_ == 4) { if (kw_ <= 3) { if (kw2_) KERNEL(4, 3, 4); else KERNEL(4, 3, 0); }               \
+                             else { if (kw2_) KERNEL(4, 4, 4); else KERNEL(4, 4, 0); } }                      \
+        else { if (kw_ <= 3) { if (kw2_) KERNEL(7, 3, 4); else KERNEL(7, 3, 0); }                             \
+               else { if (kw2_) KERNEL(7, 4, 4); else KERNEL(7, 4, 0); } }                                    \
+    } while (0)
+
+OG_API int OG_LP_NAME(og_conv_band)(const void *x, const void *w_packed, const float *bias, const void *skip, const void *x2, void *out,
+                                    int N, int Hin, int Win, int Cin, int Cout, int stride, int relu, int H2, int W2, int Cin2,
+                                    int stride2, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv_band");
+    const OgBandLayerDesc d = {x, w_packed, bias, skip, x2, out, N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2};
+    BandLayer a;
+    BandPlan p;
+    const int rc = fill_layer(name, a, p, d);
+    if (rc != OG_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *stamps = nullptr;
+#ifdef OG_BAND_STAMPS
+    if (g_band_stamps) stamps = g_band_stamps + (size_t)(g_band_launch++) * 4096 * 8;
+#endif
+#define BAND_LAUNCH(PT_, KW_, KW2_)                                                                                   \
+    do {                                                                                                              \
+        static OgAttrOnce attr_;                                                                                      \
+        if (attr_.need())                                                                                             \
+            (void)hipFuncSetAttribute((const void *)conv_band_kernel<PT_, KW_, KW2_>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);                           \
+        hipLaunchKernelGGL((conv_band_kernel<PT_, KW_, KW2_>), dim3((unsigned)p.grid), dim3(2 * 64 * kWaves), p.lds_bytes, st, a, stamps); \
+    } while (0)
+    BAND_DISPATCH(BAND_LAUNCH, p.pt, a.kw, a.kw2);
+#undef BAND_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+namespace {
+// Plans a chained launch: fills `args` (layers, LDS layout), -> status; pt / kw / kw2 / lds / grid describe the launch.
+int chain_plan(const char *name, const OgBandLayerDesc *layers, int n_layers, ChainArgs &args, int &pt, int &kw, int &kw2, int &lds, int &grid)
+{
+    OG_REQUIRE(layers, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers, OG_EUNSUPPORTED, "%s: 1 to %d layers per launch (got %d)", name, kMaxLayers, n_layers);
+    args = ChainArgs{};
+    pt = kw = kw2 = 0;
+    int max_total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        BandPlan p;
+        const int rc = fill_layer(name, args.layer[l], p, layers[l]);
+        if (rc != OG_OK) return rc;
+        BandLayer &a = args.layer[l];
+        for (int e = 0; e < l; ++e) {
+            if (layers[l].x == layers[e].out) a.in_chain |= 1;
+            if (layers[l].skip && layers[l].skip == layers[e].out) a.in_chain |= 2;
+            if (layers[l].x2 && layers[l].x2 == layers[e].out) a.in_chain |= 4;
+            OG_REQUIRE(layers[l].out != layers[e].out, OG_EINVAL, "%s: layers %d and %d write the same buffer", name, e, l);
+        }
+        OG_REQUIRE(l == 0 || layers[l].x == layers[l - 1].out, OG_EUNSUPPORTED, "%s: layer %d must read layer %d's output", name, l, l - 1);
+        OG_REQUIRE(l == 0 || a.N == args.layer[0].N, OG_EINVAL, "%s: layers of one launch share the batch size", name);
+        pt = p.pt > pt ? p.pt : pt;
+        kw = a.kw > kw ? a.kw : kw;
+        kw2 = a.kw2 > kw2 ? a.kw2 : kw2;
+        max_total = a.total > max_total ? a.total : max_total;
+    }
+    // one column-block count for the launch: the layers that would choose a smaller one are laid out for it
+    lds = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int need = band_lds(args.layer[l], pt);
+        lds = need > lds ? need : lds;
+    }
+    OG_REQUIRE(lds <= kMaxLds, OG_EUNSUPPORTED, "%s: the layers do not fit one LDS plan (%d bytes)", name, lds);
+    args.n_layers = n_layers;
+    args.word_off = (lds + 15) & ~15;
+    lds = args.word_off + 16;
+    // one workgroup per role of the widest layer, at most one per CU (every holder resident in the common case; with fewer
+    // resident workgroups each one only takes more roles)
+    grid = max_total < og_cu_count() ? max_total : og_cu_count();
+    grid = (grid + 7) / 8 * 8;
+    return OG_OK;
+}
+}  // namespace
+
+#ifndef OG_DT_F16
+// 1 when og_conv_band_chain_* serves the list as one launch (same checks, nothing runs), else 0 (og_last_error says why)
+OG_API int og_conv_band_chain_supported(const OgBandLayerDesc *layers, int n_layers)
+{
+    static thread_local ChainArgs args;
+    int pt, kw, kw2, lds, grid;
+    return chain_plan("og_conv_band_chain_supported", layers, n_layers, args, pt, kw, kw2, lds, grid) == OG_OK;
+}
+#endif
+
+// A chain of dependent layers in ONE launch: layer l reads what layer l-1 wrote (skip / x2 of a layer may be the `out` of any
+// EARLIER layer of the list, or tensors complete before the launch; the outputs must be distinct buffers).
+OG_API int OG_LP_NAME(og_conv_band_chain)(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv_band_chain");
+    OG_REQUIRE(workspace, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(workspace_bytes >= (size_t)(kMaxLayers * 8 + kMaxLayers * kMaxImages + 2) * kSyncStride * sizeof(int) &&
+                   (uintptr_t)workspace % 128 == 0,
+               OG_ENOSPC, "%s: workspace too small or not 128-byte aligned (og_conv_band_chain_workspace_bytes)", name);
+    static thread_local ChainArgs args;
+    int pt, kw, kw2, lds, grid;
+    const int rc = chain_plan(name, layers, n_layers, args, pt, kw, kw2, lds, grid);
+    if (rc != OG_OK) return rc;
+    args.sync = (int *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *stamps = nullptr;
+#ifdef OG_BAND_STAMPS
+    if (g_band_stamps) { stamps = g_band_stamps + (size_t)g_band_launch * 4096 * 8; g_band_launch += n_layers; }
+#endif
+#define CHAIN_LAUNCH(PT_, KW_, KW2_)                                                                                  \
+    do {                                                                                                              \
+        static OgAttrOnce attr_;                                                                                      \
+        if (attr_.need())                                                                                             \
+            (void)hipFuncSetAttribute((const void *)conv_band_chain_kernel<PT_, KW_, KW2_>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds + 32);                      \
+        hipLaunchKernelGGL((conv_band_chain_kernel<PT_, KW_, KW2_>), dim3((unsigned)grid), dim3(2 * 64 * kWaves), lds, st, args, stamps); \
+    } while (0)
+    BAND_DISPATCH(CHAIN_LAUNCH, pt, kw, kw2);
+#undef CHAIN_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}

@@ -79,6 +79,17 @@ CONV_PW_MIN_PIXELS = int(os.environ.get('OG_CONV_PW_MIN_PIXELS', '8192'))
 # = 3 200 pixels: 20 x 4 tiles split 3 ways along K)
 CONV_TILED_MIN_PIXELS = int(os.environ.get('OG_CONV_TILED_MIN_PIXELS', '2048'))
 CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
+# OG_CONV_BAND_MAX_PIXELS = P (default 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with at
+# most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: K split over the waves of a
+# workgroup, no slabs / tickets) where it serves the shape -- 1024 = the 10x10 / 5x5 levels at batch 8 -- and with
+# OG_CONV_BAND_CHAIN=1 runs of such residual blocks go out as ONE chained launch (og_conv_band_chain_*).  Measured (round 4,
+# EXPERIMENTS.md): a 5x5 layer alone 12.5 -> 8.2 us (7.4 chained), a 10x10 layer 13.7 -> 11.7, and the whole step 1-4 % SLOWER:
+# a band workgroup owns its CU (8 waves x ~240 registers), so the up1 branches that run beside the bottom of the hourglass
+# wait for it instead of sharing the chip, and a chained launch holds all 256 CUs for its ~100 us.  Off by default; the kernels,
+# their tests and tools stay (the split-K kernel keeps these layers).
+CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '0'))
+CONV_BAND_CHAIN = int(os.environ.get('OG_CONV_BAND_CHAIN', '0'))
+_chain_ws = {}
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
@@ -138,6 +149,7 @@ class _Conv:
         self.b = b.to(dtype)
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
         self.w_tiled = None          # weights in og_conv3x3_tiled_*'s layout, made on first use
+        self.w_band = None           # weights (+ projection) in og_conv_band_*'s fragment order, made on first use
         self.fused = fused and w.shape[0] % 8 == 0
         strides = ((1, 1), (2, 2)) if int(os.environ.get('OG_ENGINE_CONV_S2', '1')) else ((1, 1),)
         self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) in strides
@@ -173,6 +185,8 @@ class _Conv:
         if self.hip3x3:
             st = self.stride[0]
             pixels = n * ((h - 1) // st + 1) * ((w - 1) // st + 1)
+            if self.band_ok(x):
+                return self.band(x, skip)
             # stride 2: the split-K kernel wins where M is small (40x40 -> 20x20 and below at bs8: 30 / 15 / 12 us against
             # MIOpen + epilogue 48 / 30 / 26); the large stride-2 layers stay on MIOpen (CK is 1.2-1.6x faster there)
             if (st == 1 and (CONV_TILED & 1) and pixels >= CONV_TILED_MIN_PIXELS and self.w.shape[0] % 128 == 0
@@ -188,6 +202,76 @@ class _Conv:
                     skip = skip.contiguous(memory_format=torch.channels_last)
                 return self._tiled_s2(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
+
+    def band_ok(self, x, x2=None, proj=None):
+        """This 3x3 layer (+ the 1x1 projection `proj` of x2, residual.skip) can run on og_conv_band_* for input x."""
+        return x.is_cuda and self.band_ok_shape(tuple(x.shape), tuple(x2.shape) if x2 is not None else None, proj, x.dtype)
+
+    def band_ok_shape(self, x_shape, x2_shape, proj, dtype):
+        if not (CONV_BAND_MAX_PIXELS and self.hip3x3 and dtype == self.w.dtype) or _WHATIF:
+            return False
+        n, c, h, w = x_shape
+        st = self.stride[0]
+        if c != self.w.shape[1] or n * ((h - 1) // st + 1) * ((w - 1) // st + 1) > CONV_BAND_MAX_PIXELS:
+            return False
+        h2 = w2 = c2 = 0
+        st2 = 1
+        if proj is not None:
+            if tuple(proj.w.shape[2:]) != (1, 1) or tuple(proj.pad) != (0, 0) or x2_shape is None:
+                return False
+            _, c2, h2, w2 = x2_shape
+            st2 = proj.stride[0]
+        # one round of workgroups: a layer cut into more bands than that (stride 2 from 20x20: 576) is slower than the split-K kernel
+        return 0 < _lib.load().og_conv_band_supported(n, h, w, c, self.w.shape[0], st, h2, w2, c2, st2) <= 320
+
+    def band_pack(self, device, proj=None):
+        """The layer's weights (+ the projection's) in og_conv_band_*'s fragment order, packed once (never inside graph capture)."""
+        if self.w_band is None:
+            assert not torch.cuda.is_current_stream_capturing(), 'weights must be packed before graph capture'
+            lib = _lib.load()
+            cout, c = self.w.shape[0], self.w.shape[1]
+            c2 = proj.w.shape[1] if proj is not None else 0
+            self.w_band = torch.empty(cout * (9 * c + c2), dtype=self.w.dtype, device=self.w.device)
+            w2 = proj.w.reshape(cout, c2).contiguous() if proj is not None else None
+            _lib.check(lib.og_conv_band_pack_w16(_lib.ptr(self.w), _lib.ptr(w2) if w2 is not None else None, c, cout, c2,
+                                                 _lib.ptr(self.w_band), _lib.stream_ptr(device)), lib)
+        return self.w_band
+
+    def band_desc(self, x, out, skip=None, x2=None, proj=None):
+        """This layer as one entry of an og_conv_band_chain_* launch (tensors channels-last)."""
+        n, c, h, w = x.shape
+        h2 = w2 = c2 = 0
+        st2 = 1
+        if proj is not None:
+            _, c2, h2, w2 = x2.shape
+            st2 = proj.stride[0]
+        return _lib.BandLayerDesc(_lib.ptr(x), _lib.ptr(self.band_pack(x.device, proj)), _lib.ptr(self.b32),
+                                  _lib.ptr(skip) if skip is not None else None, _lib.ptr(x2) if proj is not None else None,
+                                  _lib.ptr(out), n, h, w, c, self.w.shape[0], self.stride[0], int(self.relu), h2, w2, c2, st2)
+
+    def band(self, x, skip=None, x2=None, proj=None):
+        """act(conv3x3(x) (+ conv1x1(x2) of `proj`) + bias (+ skip)) on og_conv_band_* (bias = the sum of both folded biases when a
+        projection rides along, see _Residual)."""
+        n, c, h, w = x.shape
+        cout, st = self.w.shape[0], self.stride[0]
+        lib = _lib.load()
+        self.band_pack(x.device, proj)
+        x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+        if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+        h2 = w2_ = c2 = 0
+        st2 = 1
+        if proj is not None:
+            x2 = x2 if x2.is_contiguous(memory_format=torch.channels_last) else x2.contiguous(memory_format=torch.channels_last)
+            _, c2, h2, w2_ = x2.shape
+            st2 = proj.stride[0]
+        out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        _lib.check(_lib.lp(lib, 'og_conv_band', x.dtype)(
+            _lib.ptr(x), _lib.ptr(self.w_band), _lib.ptr(self.b32), _lib.ptr(skip) if skip is not None else None,
+            _lib.ptr(x2) if proj is not None else None, _lib.ptr(out), n, h, w, c, cout, st, int(self.relu), h2, w2_, c2, st2,
+            _lib.stream_ptr(x.device)), lib)
+        return out
 
     def pointwise_ok(self, x):
         """This 1x1 layer can run on og_conv1x1_tiled_* for input x (large levels, channel multiples the kernel serves)."""
@@ -316,6 +400,8 @@ class _Residual:
         if after_c1 is not None:
             after_c1()
         n, c, h, w = y.shape
+        if self.skip is not None and self.c2.band_ok(y, x2=x, proj=self.skip):
+            return self.c2.band(y, x2=x, proj=self.skip)      # the projection rides along K; its bias is in c2's
         if self.w_cat is not None and n * h * w <= CONV3X3_MAX_PIXELS and not _WHATIF:
             return self._proj(y, x)
         if self.skip is None:
@@ -347,9 +433,87 @@ def _seq(mods, dtype, fused):
     return [_Residual(m, dtype, fused) for m in mods]
 
 
-def _run(seq, x):
-    for f in seq:
-        x = f(x)
+def _chain_workspace(device):
+    """The zero-initialised words of og_conv_band_chain_* launches, one set per (device, engine, concurrent branch): launches
+    of one branch are stream-ordered, and every launch leaves its words zero."""
+    key = (device.index, _issuer.engine, _issuer.branch)
+    buf = _chain_ws.get(key)
+    if buf is None:
+        assert not torch.cuda.is_current_stream_capturing(), 'the chain workspace must exist before graph capture'
+        buf = _chain_ws[key] = torch.zeros(int(_lib.load().og_conv_band_chain_workspace_bytes()), dtype=torch.uint8, device=device)
+    return buf
+
+
+def _chain_from(blocks, i, x, after_first=None):
+    """The longest run of convolutions starting at residual block i that og_conv_band_chain_* serves as ONE launch (stride-1 3x3
+    layers on the band kernel's smallest tile, <= 16 layers): -> (output, index of the first block not consumed) or None.
+    A block whose conv1 has stride 2 may open a run with its conv2 (+ projection)."""
+    if not (CONV_BAND_CHAIN and CONV_BAND_MAX_PIXELS and x.is_cuda) or _WHATIF:
+        return None
+    cl = torch.channels_last
+    descs, keep, cur, j, opened_s2 = [], [], x, i, None
+    while j < len(blocks) and len(descs) + 2 <= 16:
+        r = blocks[j]
+        if not isinstance(r, _Residual):
+            break
+        c1s1 = tuple(r.c1.stride) == (1, 1)
+        n, _, h, w = cur.shape
+        st = r.c1.stride[0]
+        y_shape = (n, r.c1.w.shape[0], (h - 1) // st + 1, (w - 1) // st + 1)
+        if not r.c1.band_ok(cur) or (not c1s1 and descs):
+            break
+        proj = r.skip
+        if not r.c2.band_ok_shape(y_shape, cur.shape if proj is not None else None, proj, cur.dtype):
+            break
+        if not cur.is_contiguous(memory_format=cl):
+            cur = cur.contiguous(memory_format=cl)
+        y = torch.empty(y_shape, dtype=cur.dtype, device=cur.device, memory_format=cl)
+        if c1s1:
+            descs.append(r.c1.band_desc(cur, y))
+        else:
+            # stride 2: its own launch (into y); the run opens with conv2.  Only where the next block can follow.
+            nxt = blocks[j + 1] if j + 1 < len(blocks) else None
+            if not (isinstance(nxt, _Residual) and tuple(nxt.c1.stride) == (1, 1)
+                    and nxt.c1.band_ok_shape((n, r.c2.w.shape[0]) + tuple(y_shape[2:]), None, None, cur.dtype)):
+                break
+            opened_s2 = (r.c1, cur, y)
+        out = torch.empty((n, r.c2.w.shape[0]) + tuple(y_shape[2:]), dtype=cur.dtype, device=cur.device, memory_format=cl)
+        descs.append(r.c2.band_desc(y, out, skip=cur if proj is None else None, x2=cur if proj is not None else None, proj=proj))
+        keep += [cur, y, out]
+        cur, j = out, j + 1
+    # the library plans the list exactly as the launch will (one tile size, one LDS layout): shorten the run until it fits
+    while len(descs) >= 2 and not _lib.band_chain_supported(descs):
+        descs, j = descs[:-2], j - 1
+        cur = keep[3 * (j - i) - 1] if j > i else x
+    if len(descs) < 2:
+        return None
+    if opened_s2:
+        c1, xin, y = opened_s2
+        lib = _lib.load()
+        nn, cc, hh, ww = xin.shape
+        _lib.check(_lib.lp(lib, 'og_conv_band', xin.dtype)(
+            _lib.ptr(xin), _lib.ptr(c1.band_pack(xin.device)), _lib.ptr(c1.b32), None, None, _lib.ptr(y), nn, hh, ww, cc, c1.w.shape[0],
+            c1.stride[0], int(c1.relu), 0, 0, 0, 1, _lib.stream_ptr(xin.device)), lib)
+        if after_first is not None:
+            after_first()
+            after_first = None
+    _lib.band_chain(descs, cur.dtype, _chain_workspace(cur.device), cur.device)
+    if after_first is not None:
+        after_first()
+    return cur, j
+
+
+def _run(seq, x, after_first=None):
+    """The blocks of `seq` in order; runs of small-level residuals go out as chained launches.  after_first: called once the
+    first kernel has been launched (fork point of a side branch, _Level)."""
+    i = 0
+    while i < len(seq):
+        run = _chain_from(seq, i, x, after_first if i == 0 else None)
+        if run is None:
+            x = seq[i](x, after_c1=after_first) if (i == 0 and after_first is not None) else seq[i](x)
+            i += 1
+        else:
+            x, i = run
     return x
 
 
@@ -362,9 +526,10 @@ class _Level:
 
     def _lower(self, x, after_first=None):
         """-> the input of low3's LAST residual (that one runs after the join: the merge may ride on its epilogue)"""
-        low = self.low1[0](x, after_c1=after_first)
-        low = _run(self.low1[1:], low)
-        low = self.low2(low) if isinstance(self.low2, _Level) else _run(self.low2, low)
+        if not isinstance(self.low2, _Level):      # the bottom of the hourglass: one list, so that a chained launch can span it
+            return _run(self.low1 + self.low2 + self.low3[:-1], x, after_first)
+        low = _run(self.low1, x, after_first)
+        low = self.low2(low)
         return _run(self.low3[:-1], low)
 
     def __call__(self, x):
@@ -424,7 +589,11 @@ class _Level:
         else:
             low = self._lower(x)
             up = _run(self.up1, x)
-        low = self.low3[-1](low, merge_up=up if self.fused and up.is_contiguous(memory_format=torch.channels_last) else None)
+        run = _chain_from(self.low3[-1:], 0, low) if self.fused else None     # small levels: the block's two convolutions as one launch
+        if run is not None:
+            low = run[0]
+        else:
+            low = self.low3[-1](low, merge_up=up if self.fused and up.is_contiguous(memory_format=torch.channels_last) else None)
         if low is None:
             return up   # up += nearest_x2(low3(low)) happened in the last convolution's epilogue
         if self.fused:  # up += nearest_x2(low) in one pass
@@ -439,9 +608,11 @@ class _Level:
 class InferenceEngine:
     """engine = InferenceEngine(model, batch, H, W); feats = engine(images)  (images fp32 NCHW on device).
 
-    `batch` is the number of images per call (2x the evaluation batch with flip-test)."""
+    `batch` is the number of images per call (2x the evaluation batch with flip-test).  dtype: torch.float16 (default: the
+    reference evaluates in fp16 through apex O2, evaluate.py:92,198-201), torch.bfloat16 (same kernels, same MFMA rate, 8x the
+    rounding error) or torch.float32 (plain torch ops: the checking path)."""
 
-    def __init__(self, model, batch, height, width, dtype=torch.bfloat16, device='cuda:0', feat_stage=-1,
+    def __init__(self, model, batch, height, width, dtype=torch.float16, device='cuda:0', feat_stage=-1,
                  use_graph=True):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
         global _n_engines

@@ -438,6 +438,159 @@ def test_conv3x3_halo_kernel_several_items_per_workgroup(dev):
     assert " passed" in r.stdout
 
 
+# (N, Hin, Win, Cin, Cout, stride, projection (H2, W2, Cin2, stride2) or None)
+BAND_SHAPES = [(8, 5, 5, 512, 512, 1, None), (8, 10, 10, 384, 384, 1, None), (2, 20, 20, 384, 384, 1, None),
+               (8, 10, 10, 384, 512, 2, None), (2, 20, 20, 384, 384, 2, None), (8, 5, 5, 512, 512, 1, (10, 10, 384, 2)),
+               (8, 5, 5, 384, 384, 1, (5, 5, 512, 1)), (3, 7, 9, 128, 64, 1, None), (1, 4, 4, 64, 64, 1, None),
+               (2, 6, 12, 256, 128, 2, None), (1, 3, 40, 64, 48, 1, None), (2, 9, 11, 96, 80, 1, (9, 11, 64, 1))]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", BAND_SHAPES)
+def test_conv_band_matches_torch(dev, shape, dtype):
+    """og_conv_band_* (band-resident: K split over the waves of a workgroup, partial tiles summed in LDS; csrc/conv_band.hip) vs an
+    fp32 torch convolution of the same 16-bit operands (+ the residual's 1x1 projection, models/hourglass_104.py:63-79): with and
+    without the residual operand / ReLU, stride 1 and 2, one band and several, channel counts that leave lanes and waves idle."""
+    import torch.nn.functional as F
+    n, h, w, cin, cout, st, proj = shape
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 1000 + w * 10 + cin + cout + st)
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    base = F.conv2d(x.float(), wt.float(), bias, st, 1)
+    ho, wo = base.shape[2:]
+    h2 = w2 = c2 = 0
+    st2, x2, wp = 1, None, None
+    if proj is not None:
+        h2, w2, c2, st2 = proj
+        x2 = torch.randn(n, c2, h2, w2, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+        wp = (torch.randn(cout, c2, generator=g) * (1.0 / c2) ** 0.5).to(dev).to(dtype).contiguous()
+        base = base + F.conv2d(x2.float(), wp.float().view(cout, c2, 1, 1), None, st2, 0)
+    assert lib.og_conv_band_supported(n, h, w, cin, cout, st, h2, w2, c2, st2) > 0
+    packed = torch.empty(cout * (9 * cin + c2), dtype=dtype, device=dev)
+    _lib.check(lib.og_conv_band_pack_w16(_lib.ptr(wt), _lib.ptr(wp) if wp is not None else None, cin, cout, c2, _lib.ptr(packed),
+                                         _lib.stream_ptr(dev)), lib)
+    skip = torch.randn(n, cout, ho, wo, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    fn = _lib.lp(lib, 'og_conv_band', dtype)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    for use_skip, relu in ((True, 1), (False, 0), (False, 1)):
+        ref = base + skip.float() if use_skip else base
+        if relu:
+            ref = F.relu(ref)
+        out = torch.full_like(skip, float('nan'))
+        for _ in range(2):
+            _lib.check(fn(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if use_skip else None,
+                          _lib.ptr(x2) if x2 is not None else None, _lib.ptr(out), n, h, w, cin, cout, st, relu, h2, w2, c2, st2,
+                          _lib.stream_ptr(dev)), lib)
+        assert not torch.isnan(out.float()).any()
+        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, f'{shape} skip={use_skip} relu={relu}: relative error {err}'
+
+
+def _band_chain_case(dev, dtype, n, hw, chans, seed):
+    """A chain shaped like the hourglass's residuals at one level: conv1 (ReLU), conv2 + skip (ReLU), ...; channel counts from
+    `chans` (a projection along K where a residual changes its width).  -> (descs, keep-alive tensors, outputs, inputs)"""
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    cl = torch.channels_last
+    h = w = hw
+    x = torch.randn(n, chans[0], h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    descs, keep, outs, layers = [], [x], [], []
+    cur, cur_c = x, chans[0]
+    for bi, cout in enumerate(chans[1:]):
+        block_in, block_c = cur, cur_c
+        for half in (0, 1):
+            cin = cur_c
+            wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+            bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+            proj = half == 1 and block_c != cout
+            wp = (torch.randn(cout, block_c, generator=g) * (1.0 / block_c) ** 0.5).to(dev).to(dtype).contiguous() if proj else None
+            packed = torch.empty(cout * (9 * cin + (block_c if proj else 0)), dtype=dtype, device=dev)
+            _lib.check(lib.og_conv_band_pack_w16(_lib.ptr(wt), _lib.ptr(wp) if proj else None, cin, cout, block_c if proj else 0,
+                                                 _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+            out = torch.full((n, cout, h, w), float('nan'), dtype=dtype, device=dev).contiguous(memory_format=cl)
+            skip = block_in if (half == 1 and not proj) else None
+            d = _lib.BandLayerDesc(_lib.ptr(cur), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if skip is not None else None,
+                                   _lib.ptr(block_in) if proj else None, _lib.ptr(out), n, h, w, cin, cout, 1, 1,
+                                   h if proj else 0, w if proj else 0, block_c if proj else 0, 1)
+            descs.append(d)
+            layers.append((cur, wt, bias, skip, block_in if proj else None, wp))
+            keep += [wt, bias, packed, out] + ([wp] if proj else [])
+            outs.append(out)
+            cur, cur_c = out, cout
+    return descs, keep, outs, layers
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(8, 5, [512, 512, 512, 384]), (8, 10, [384, 384, 384]), (3, 7, [128, 64, 64, 96]), (2, 20, [384, 384])])
+def test_conv_band_chain_matches_layerwise(dev, case, dtype):
+    """og_conv_band_chain_* (dependent layers in ONE launch: per-XCD ticket queues, per-image completion counters, write-through
+    hand-off) vs the same layers launched one by one (bit for bit: same arithmetic) and vs fp32 torch; launched five times on one
+    workspace (it must come back zero), the sticky error word stays clear."""
+    import torch.nn.functional as F
+    n, hw, chans = case
+    lib = _lib.load()
+    descs, keep, outs, layers = _band_chain_case(dev, dtype, n, hw, chans, seed=hw * 100 + n)
+    ws = torch.zeros(lib.og_conv_band_chain_workspace_bytes(), dtype=torch.uint8, device=dev)
+    fn = _lib.lp(lib, 'og_conv_band', dtype)
+    for d in descs:      # reference: one launch per layer
+        _lib.check(fn(d.x, d.w_packed, d.bias, d.skip, d.x2, d.out, d.N, d.Hin, d.Win, d.Cin, d.Cout, d.stride, d.relu, d.H2, d.W2,
+                      d.Cin2, d.stride2, _lib.stream_ptr(dev)), lib)
+    ref = [o.clone() for o in outs]
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    for (xin, wt, bias, skip, x2, wp), r in zip(layers, ref):          # the layer-wise path itself against torch
+        t = F.conv2d(xin.float(), wt.float(), bias, 1, 1)
+        if x2 is not None:
+            t = t + F.conv2d(x2.float(), wp.float().view(wp.shape[0], -1, 1, 1))
+        if skip is not None:
+            t = t + skip.float()
+        t = F.relu(t)
+        assert ((r.float() - t).abs().max() / t.abs().max()).item() <= tol
+    for rep in range(5):
+        for o in outs:
+            o.fill_(float('nan'))
+        if rep == 3:      # uneven load: a bandwidth hog runs beside the chain
+            side = torch.cuda.Stream(dev)
+            with torch.cuda.stream(side):
+                junk = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+                junk.fill_(1)
+        _lib.band_chain(descs, dtype, ws, dev)
+        torch.cuda.synchronize()
+        for li, (o, r) in enumerate(zip(outs, ref)):
+            assert torch.equal(o, r), f'{case} launch {rep} layer {li}: chained result differs from the layer-wise launch'
+        assert int(ws.view(torch.int32).abs().sum().item()) == 0, 'the launch must leave its workspace zero (error word included)'
+
+
+def test_conv_band_chain_rejects_bad_lists(dev):
+    lib = _lib.load()
+    descs, keep, outs, _ = _band_chain_case(dev, torch.float16, 2, 5, [64, 64], seed=1)
+    ws = torch.zeros(lib.og_conv_band_chain_workspace_bytes(), dtype=torch.uint8, device=dev)
+    arr = (_lib.BandLayerDesc * 2)(descs[1], descs[0])                   # layer 1 does not read layer 0
+    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == -4
+    arr = (_lib.BandLayerDesc * 2)(*descs)
+    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), 128, _lib.stream_ptr(dev)) == -2      # workspace too small
+    assert lib.og_conv_band_chain_f16(arr, 17, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == -4
+    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == 0
+    torch.cuda.synchronize()
+
+
+def test_conv_band_rejects_bad_arguments(dev):
+    lib = _lib.load()
+    assert lib.og_conv_band_supported(8, 5, 5, 48, 64, 1, 0, 0, 0, 0) == 0          # Cin % 32
+    assert lib.og_conv_band_supported(8, 5, 5, 1024, 64, 1, 0, 0, 0, 0) == 0        # more chunks than waves
+    assert lib.og_conv_band_supported(8, 5, 200, 64, 64, 1, 0, 0, 0, 0) == 0        # a row wider than a band
+    assert lib.og_conv_band_supported(8, 5, 5, 64, 64, 3, 0, 0, 0, 0) == 0          # stride
+    assert lib.og_conv_band_supported(8, 5, 5, 64, 64, 1, 7, 7, 64, 1) == 0         # projection grid does not match
+    x = torch.zeros(1, 64, 4, 4, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.zeros(64, device=dev)
+    assert lib.og_conv_band_bf16(_lib.ptr(x), _lib.ptr(x), _lib.ptr(b), None, None, _lib.ptr(x), 1, 4, 4, 48, 64, 1, 1, 0, 0, 0, 1,
+                                 _lib.stream_ptr(dev)) == -4
+    assert lib.og_conv_band_bf16(None, _lib.ptr(x), _lib.ptr(b), None, None, _lib.ptr(x), 1, 4, 4, 64, 64, 1, 1, 0, 0, 0, 1,
+                                 _lib.stream_ptr(dev)) == -1
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 32), (2, 64, 96), (1, 128, 64)])
 def test_stem7x7_matches_torch(dev, shape):
     """og_stem7x7_bf16 (fp32 NCHW in, conv 7x7 s2 p3 + bias + ReLU, bf16 NHWC out) vs an fp32 torch convolution of the
@@ -685,10 +838,12 @@ def test_engine_f16_matches_reference_golden(dev):
             assert err <= 4e-3, f'{name} fp16: relative error {err}'
 
 
-@pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"}])
+@pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"},
+                                   {"OG_CONV_BAND_MAX_PIXELS": "1024"}, {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}])
 def test_engine_schedule_knobs(dev, knobs):
     """The engine's kept A/B switches (read at import): merges as their own launches instead of on the producing convolution's
-    epilogue, up1 branch captured before the trunk below the fork -- the graph-engine tests again in a child process."""
+    epilogue, up1 branch captured before the trunk below the fork, the small levels on the band-resident kernel (one launch per
+    layer / chained launches) -- the graph-engine tests again in a child process."""
     import os
     import subprocess
     import sys
