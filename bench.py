@@ -26,16 +26,9 @@ import os
 import sys
 import time
 
-# One MIOpen user database per rank: with N ranks on a node every process runs MIOpen's kernel search while the engine
-# is built, and they would otherwise all write the same sqlite files under ~/.config/miopen.
-# the engine's HIP graph replays its branches on the runtime's hardware queues; 4 (the default) measured best (DESIGN 8)
+# the engine's HIP graph replays its branches on the runtime's hardware queues; 4 (the default) measured best (DESIGN 4)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory (see offsetguided_amd/__init__.py)
-if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
-    _db = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'miopen_rank%s' % os.environ.get('LOCAL_RANK', '0'))
-    os.makedirs(_db, exist_ok=True)
-    os.environ['MIOPEN_USER_DB_PATH'] = _db
-    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', _db)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -44,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0    # the guide's measured float4-copy rate (79 % of the spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 FLOP_PER_IMAGE = 732.78e9       # 2 x 366.39 GMAC, convs only, 640x640
 K1_BYTES_PER_IMAGE = 27_889_280  # 17*640*640*4 read + offset gathers + limbs write
@@ -63,11 +57,12 @@ def parse():
     ap.add_argument('--dtype', choices=['bf16', 'f16'], default='f16',
                     help='engine arithmetic: f16 (default: the reference evaluates in fp16 through apex O2, evaluate.py:92,198-201) or '
                          'bf16; same MFMA rate, fp16 is 8x closer to the fp32 module')
+    ap.add_argument('--no-harness', action='store_true', help='skip the evaluate.run_images figure (raw uint8 host images -> result dicts)')
     ap.add_argument('--no-extras', action='store_true',
                     help='headline region only: skip the decoder-only / backbone-only / conv / HBM-cold / flip measurements')
     ap.add_argument('--allow-diagnostic', action='store_true',
-                    help='run although a timing-only switch that produces WRONG RESULTS is set (OG_ENGINE_WHATIF, OG_DECODER_LIB, '
-                         'OG_BENCH_FAIL_RANK): the JSON line then carries "diagnostic": true and is not a measurement')
+                    help='run although a switch that produces WRONG RESULTS or loads a foreign library is set (OG_ENGINE_WHATIF, '
+                         'OG_DECODER_LIB): the JSON line then carries "diagnostic": true and is not a measurement')
     ap.add_argument('--no-alt-dtype', '--no-f16', dest='no_alt_dtype', action='store_true',
                     help='skip the figure for the other 16-bit arithmetic (bf16 beside the fp16 headline, or fp16 beside --dtype bf16)')
     ap.add_argument('--dry-run', action='store_true',
@@ -144,6 +139,55 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def current_sclk_mhz():
+    """The shader clock level sysfs marks as current ('*' in pp_dpm_sclk) of the first GPU, or None."""
+    import glob
+    for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+        try:
+            for ln in open(f):
+                if ln.strip().endswith('*'):
+                    return int(''.join(ch for ch in ln.split(':', 1)[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def numa_nodes():
+    """[(node id, [cpu ids])] from sysfs, nodes that have CPUs only."""
+    import glob
+    out = []
+    for d in sorted(glob.glob('/sys/devices/system/node/node[0-9]*'), key=lambda p: int(p.rsplit('node', 1)[1])):
+        try:
+            spec = open(os.path.join(d, 'cpulist')).read().strip()
+        except OSError:
+            continue
+        cpus = []
+        for part in filter(None, spec.split(',')):
+            lo, _, hi = part.partition('-')
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            out.append((int(d.rsplit('node', 1)[1]), cpus))
+    return out
+
+
+def pin_rank(local_rank, world):
+    """One process per GPU, eight of them on one host with a 6 ms step: keep a rank's threads (launch thread, pinned-copy
+    helpers, the CPU baseline's workers stay out of this) on the NUMA node of its GPU.  The GPUs of an 8-GPU MI355X node hang
+    off the host's NUMA nodes in device order (GPU 0-3 socket 0, 4-7 socket 1; with NPS4: two per node), so rank r gets node
+    r * nodes // world.  Runs BEFORE the process makes any HIP call; OG_BENCH_NUMA=0 switches it off.  -> description or None."""
+    if os.environ.get('OG_BENCH_NUMA', '1') == '0' or world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return None
+    nodes = numa_nodes()
+    if len(nodes) < 2:
+        return None
+    node, cpus = nodes[min(local_rank * len(nodes) // world, len(nodes) - 1)]
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return {'node': node, 'cpus': len(allowed)}
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) through torch.distributed.run and relay
     rank 0's JSON line.  Runs BEFORE this process makes any HIP call (the parent never touches a GPU; counting devices
@@ -167,6 +211,8 @@ def launch_ranks(a):
 
 def dry_run(a, sharding):
     """The N-rank control plane without a GPU: same rendezvous, barriers and MAX-reduce as the real run."""
+    rank, local_rank, world = sharding.env_rank()
+    numa = pin_rank(local_rank, world)
     rank, _, world = sharding.init(backend='gloo')
     if os.environ.get('OG_BENCH_FAIL_RANK') == str(rank):   # test aid: a rank that dies before the first barrier
         sys.exit(f'bench.py: rank {rank} told to fail (OG_BENCH_FAIL_RANK)')
@@ -179,7 +225,7 @@ def dry_run(a, sharding):
     if rank == 0:
         print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps,
                           'warmup': a.warmup, 'ms_per_step': None, 'dry_run': True, 'elapsed_s': round(elapsed, 4),
-                          'rccl': group, 'knobs': knobs(), **({'diagnostic': True} if diagnostic_switches() else {})}))
+                          'rccl': group, 'numa': numa, 'knobs': knobs(), **({'diagnostic': True} if diagnostic_switches() else {})}))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -200,8 +246,9 @@ def main():
     from offsetguided_amd import sharding
     if a.dry_run:
         return dry_run(a, sharding)
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
     rank, local_rank, world = sharding.env_rank()
+    numa = pin_rank(local_rank, world)          # before the first HIP call of this process
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
     # OG_BENCH_SHARE_DEVICE=1 (test aid for 1-GPU boxes): all ranks on device 0, control plane over gloo
     share = os.environ.get('OG_BENCH_SHARE_DEVICE') == '1'
     dev = torch.device('cuda', 0 if share else local_rank)
@@ -228,6 +275,7 @@ def main():
 
         def __init__(self, flip, inflight=1, dtype=None):
             self.flip = flip
+            self.host_s = []
             self.nb = a.batch * (2 if flip else 1)
             dtype = dtype or a.dtype
             self.engines = [models.InferenceEngine(model, self.nb, a.size, a.size, dtype=torch.float16 if dtype == 'f16' else torch.bfloat16, device=dev,
@@ -256,6 +304,7 @@ def main():
             dec_stream = torch.cuda.Stream(dev) if a.overlap else main_stream
             pending, out = None, None
             for i in range(first, first + n):
+                t_host = time.perf_counter()
                 feats = self.features(i)
                 if a.overlap:
                     ready = torch.cuda.Event()
@@ -265,6 +314,7 @@ def main():
                         t.record_stream(dec_stream)
                 with torch.cuda.stream(dec_stream):
                     nxt = self.proc.submit(feats, flip_test=self.flip)
+                self.host_s.append(time.perf_counter() - t_host)     # host time to ENQUEUE one step (no wait in it)
                 if pending is not None:
                     out = pending.result()
                 pending = nxt
@@ -294,6 +344,7 @@ def main():
             self.run_steps(max(warmup, 1))
             sharding.barrier(dev)
             _lib.profile_start()
+            self.host_s = []
             t0 = time.perf_counter()
             poses = self.run_steps(steps, first=warmup)
             sharding.barrier(dev)
@@ -303,6 +354,7 @@ def main():
     pipe = Pipeline(a.flip, a.inflight)
     engine, proc, maps, images, nb = pipe.engine, pipe.proc, pipe.maps, pipe.images, pipe.nb
     poses, elapsed_rank, elapsed, stage_us = pipe.timed_region(a.steps, a.warmup)
+    pipe_host = list(pipe.host_s)
     per_rank = sharding.gather_to_rank0([round(a.batch * a.steps / elapsed_rank, 2)])   # control plane only
 
     def timed(fn, n):
@@ -346,12 +398,20 @@ def main():
                 _lib.check(conv_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
                                                      _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
             timed(conv_once, 5)
+            # the chip lowers its clock under sustained MFMA load (MI355X_MICROARCH.md "DVFS give-back"): a 3-launch burst from an
+            # idle chip runs at a higher clock than the 30 back-to-back launches the figure is quoted on -- both are reported,
+            # with the shader clock sysfs shows before and after (best effort: absent on boxes that hide it)
+            time.sleep(0.25)
+            burst_us = timed(conv_once, 3) * 1e3
+            sclk_before = current_sclk_mhz()
             conv_us = timed(conv_once, 30) * 1e3
+            sclk_after = current_sclk_mhz()
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
                 'kernel': 'C1 = og_conv3x3_tiled_' + a.dtype + ' (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
                           '256->256 layer, residual + bias + ReLU epilogue fused',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
+                'us_per_launch_burst_of_3': round(burst_us, 1), 'sclk_mhz_before_after': [sclk_before, sclk_after],
                 'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
                 'frac': round(conv_flop / (conv_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 'algorithmic_flop_per_launch': conv_flop}
@@ -378,7 +438,8 @@ def main():
         _, f_rank, f_elapsed, f_stage = fpipe.timed_region(a.steps, a.warmup)
         flip_line = {'value': round(a.batch * a.steps * world / f_elapsed, 2), 'unit': 'images/sec',
                      'ms_per_step': round(f_elapsed / a.steps * 1e3, 3),
-                     'k0_us': round(float(np.mean(f_stage['k0_flip_merge'])), 2),
+                     'k0_us': round(float(np.mean(f_stage['k0_flip_merge'])), 2) if 'k0_flip_merge' in f_stage else 0.0,   # 0: the merge rides on K1a / K1
+                     'k1a_upsample_us': round(float(np.mean(f_stage['k1a_upsample'])), 2),
                      'k1_generate_limbs_us': round(float(np.mean(f_stage['k1_generate_limbs'])), 2),
                      'workload': f'bs{a.batch} {a.size}x{a.size} + flip-test: {2 * a.batch} images through the backbone per step, '
                                  'K0 flip merge, full decoder (BASELINE configs[2])'}
@@ -399,7 +460,15 @@ def main():
                                 'bits and is what the reference evaluates in)' % (alt_dtype, alt_dtype)}
         del hpipe
 
+    # ---- the drop-in harness itself: evaluate.run_images fed raw uint8 HWC host images of mixed sizes (pageable memory) --
+    # EvalPreprocess (pinned H2D + og_rescale_pad_normalize_u8) -> engine -> PostProcess.submit -> poses_to_results
+    harness = None
+    if not a.no_extras and not a.no_harness and not a.flip and a.inflight == 1 and rank == 0:
+        torch.cuda.empty_cache()
+        harness = harness_block(a, model, dev)
+
     group = sharding.describe_group(dev)
+    host_us = 1e6 * float(np.mean(pipe_host)) if pipe_host else None
     if rank == 0:
         k1 = float(np.mean(stage_us['k1_generate_limbs']))
         k1_bytes = a.batch * K1_BYTES_PER_IMAGE * (a.size * a.size) / (640 * 640)
@@ -426,11 +495,19 @@ def main():
             'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
                                    'merge_collect_kernel',
                          'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_file,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         # against what a float4 copy reaches on this chip (6.29 TB/s, MI355X_MICROARCH.md "HBM"): the stream
+                         # kernel alone runs at ~0.85 of that; the generate_limbs boundary adds the merge / pairing launch
+                         'frac_of_achievable': round(achieved / HBM_ACHIEVABLE_GBS, 4),
+                         'traffic': traffic, 'traffic_source': traffic_file,
                          'us_per_launch': round(k1, 2), 'algorithmic_bytes_per_launch': int(k1_bytes)},
             'rccl': group,
+            'host_us_per_step': None if host_us is None else round(host_us, 1),   # host time to enqueue one step (8 ranks share one host)
+            'numa': numa,
             'knobs': knobs(),
         }
+        if harness is not None:
+            line['harness'] = harness
         if diag:
             line['diagnostic'] = True
         if 'k1_cold_us' in extras:
@@ -450,6 +527,37 @@ def main():
     if dist.is_initialized():
         sharding.barrier(dev)
         dist.destroy_process_group()
+
+
+def harness_block(a, model, dev, n_batches=24):
+    """img/s of offsetguided_amd.evaluate.run_images (reference evaluate.py:125-300) from raw host images to COCO result dicts:
+    batches of (h, w, 3) uint8 RGB arrays of eight COCO-like sizes in pageable memory; the first two batches build the engine
+    (untimed), the next `n_batches` are timed with the host clock (device synchronised on both sides)."""
+    from offsetguided_amd import evaluate
+    rng = np.random.default_rng(0)
+    sizes = [(480, 640), (427, 640), (640, 480), (375, 500), (500, 375), (640, 640), (333, 500), (612, 612)]
+    base = [rng.integers(0, 256, size=hw + (3,), dtype=np.uint8) for hw in sizes]
+    args = evaluate.evaluate_cli(['--no-pretrain', '--topk', '32', '--thre-hmp', '0.04', '--person-thre', '0.04', '--dist-max', '40',
+                                  '--batch-size', str(a.batch), '--long-edge', str(a.size), '--print-freq', '1000000000'])
+    marks = {}
+
+    def loader():
+        for b in range(n_batches + 2):
+            if b == 2:
+                torch.cuda.synchronize(dev)
+                marks['t0'] = time.perf_counter()
+            imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
+            yield imgs, [None] * a.batch, [{'image_id': b * a.batch + i} for i in range(a.batch)]
+    results, ids = evaluate.run_images(args, loader(), model=model)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - marks['t0']
+    assert len(ids) == (n_batches + 2) * a.batch
+    return {'value': round(n_batches * a.batch / dt, 2), 'unit': 'images/sec', 'batches': n_batches,
+            'ms_per_batch': round(dt / n_batches * 1e3, 3),
+            'input': f'{a.batch} raw (h, w, 3) uint8 RGB host images per batch, eight COCO-like sizes (333x500 ... 640x640), pageable memory',
+            'stages': 'EvalPreprocess (pinned staging + one H2D copy + og_rescale_pad_normalize_u8 per image) -> InferenceEngine -> '
+                      'PostProcess.submit -> annotations_inverse + COCO result dicts (evaluate.run_images, reference evaluate.py:125-300)',
+            'note': 'head outputs of the random-init network (no synthetic maps added): the decoder sees few candidates here'}
 
 
 def cpu_baseline(a, model, maps, cd):

@@ -127,24 +127,13 @@ int og_collect_limbs_full_f32(const float *scores, const int64_t *inds, const fl
 /* ---- a8+a9+a10 in ONE call: LimbsCollect.generate_limbs  decoder/collect.py:62-236 on (N,C,H,W) hi-res heatmaps ----
  * = og_nms_topk_f32 (joint_dets, decoder/heatmap.py:52-59) followed by og_collect_limbs_full_f32, same arguments and
  * bit-identical limbs.  topk_scores / topk_inds: optional (N,C,k) outputs of the joint_dets stage (both or neither).
- * flags 0: two launches queued back to back -- band top-k, then ONE kernel that merges the band lists and pairs the limbs
- *   (workgroup (image, limb type) merges its two joint planes in LDS and pairs from there; the (N,C,k) lists are written by
- *   extra workgroups of the same launch) -- the measured-fastest form on MI355X.
- * flags OG_LIMBS_SINGLE_LAUNCH: one persistent kernel -- one workgroup per CU streams a feedback-balanced share of the
- *   planes' rows (one HBM read of the heatmaps), the last workgroup to finish an image merges its candidate lists and
- *   writes the limb rows.  Shapes it does not take (W % 4 != 0, k > 64, planes much smaller than a workgroup's share of
- *   rows) silently run as flags 0.  Measured slower than flags 0 at bs8 640x640, kept
- *   as the basis of the next step.
- * flags OG_LIMBS_TAIL_IN_BAND: the band top-k launch of flags 0 does the rest as well, by last arrivers -- the band that
- *   finishes a plane last merges its lists, the plane that completes a limb type's two joint planes last pairs that limb
- *   type.  One launch, nobody waits; measured 2 us slower than flags 0 (the hand-offs are memory round trips on the path of
- *   the last plane), kept tested.  Shapes it does not take (W % 4 != 0, very large N * L) run as flags 0.
- * workspace: og_generate_limbs_workspace_bytes(N, C, H, W, k), 16-byte aligned, ZERO-FILLED ONCE by the caller
- * (hipMemset) before its first use; every call leaves it ready for the next one (any shape, any flags).  Its first
- * 64 KiB hold the only state that outlives a call (tickets, all zero between calls, and the row partition the
- * persistent kernel's feedback step maintains).  One call at a time per workspace. */
-#define OG_LIMBS_SINGLE_LAUNCH 1
-#define OG_LIMBS_TAIL_IN_BAND 2
+ * Two launches queued back to back -- band top-k, then ONE kernel that merges the band lists and pairs the limbs (shapes
+ * whose merge stage does not fit the LDS finish with og_collect_limbs_full_f32's kernel).  `flags` is reserved: pass 0 (rounds 2
+ * and 3 selected two one-launch forms there -- a persistent kernel and the merge + pairing by last arrivers of the band launch --
+ * both bit-identical and slower; they live on as tools/experiments/k1_single.inc / EXPERIMENTS.md).
+ * workspace: og_generate_limbs_workspace_bytes(N, C, H, W, k) bytes, 16-byte aligned, ZERO-FILLED by the caller
+ * (hipMemset) before its first use; every call leaves it ready for the next one (any shape).
+ */
 int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
                           const float *scales, int scales_mode, const float *jitter, int jitter_mode,
                           int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
@@ -153,6 +142,21 @@ int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lo
                           void *stream);
 
 size_t og_generate_limbs_workspace_bytes(int N, int C, int H, int W, int k);
+
+/* ---- flip-test without a merge pass: PostProcess.flip_augment (decoder/factory.py:98-146, the averaged form) folded into the
+ * loads of its two consumers.  Both take the head outputs of [images | mirrored images] (2N leading) and compute every value
+ * they read exactly as og_flip_merge_f32 would have written it -- (a + flipW(b)[perm]) / 2, x offsets negated, the limbs of
+ * `reserve_mask` un-averaged -- so the results are bit-identical to og_flip_merge_f32 followed by og_upsample_bicubic4_f32 /
+ * og_generate_limbs_f32 (2-component offsets sampled from the stride-4 map, no scale / jitter head), one pass over the
+ * 3 x 5.6 MB/img stride-4 maps and one launch fewer.
+ *   og_upsample_bicubic4_flip_f32: hm_pair (2N,C,h,w) -> dst (N,C,4h,4w); kp_perm int32[C] (config.heatmap_hflip).
+ *   og_generate_limbs_flip_f32: offs_pair (2N,2L,H/4,W/4); limb_perm / reserve_mask int32[L] (config.offset_hflip); the other
+ *     arguments, the workspace and the outputs as og_generate_limbs_f32. */
+int og_upsample_bicubic4_flip_f32(const float *hm_pair, const int32_t *kp_perm, int N, int C, int h, int w, float *dst, void *stream);
+int og_generate_limbs_flip_f32(const float *hmps_hr, const float *offs_pair, const int32_t *limb_perm, const int32_t *reserve_mask,
+                               int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp,
+                               float min_len, float resize_factor, float *topk_scores, int64_t *topk_inds, float *limbs,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,

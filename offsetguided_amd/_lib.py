@@ -15,8 +15,6 @@ if os.environ.get("OG_DECODER_LIB"):  # alternative build of the same ABI (kerne
     LIB_PATH = os.environ["OG_DECODER_LIB"]
 
 OG_OK, OG_EINVAL, OG_ENOSPC, OG_EHIP, OG_EUNSUPPORTED = 0, -1, -2, -3, -4
-OG_LIMBS_SINGLE_LAUNCH = 1
-OG_LIMBS_TAIL_IN_BAND = 2   # og_generate_limbs_f32 flags
 ABI_VERSION = 2
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
@@ -28,6 +26,8 @@ SIGNATURES = {
     "og_device_count": (_i, []),
     "og_upsample_bicubic4_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
     "og_upsample_bilinear4_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
+    "og_upsample_bicubic4_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "og_generate_limbs_flip_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_hmp_nms_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
     "og_topk_channel_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "og_nms_topk_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

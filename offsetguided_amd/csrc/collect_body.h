@@ -43,6 +43,19 @@ __device__ __forceinline__ float bilinear4_at(const float *__restrict__ p, int h
     return __builtin_fmaf(a, ly0, b * ly1);
 }
 
+// bilinear4_at over a map given by an accessor p(y, x) (the same fma chain)
+template <class F>
+__device__ __forceinline__ float bilinear4_fn(F p, int h, int w, int Y, int X)
+{
+    int x0, x1, y0, y1;
+    float lx0, lx1, ly0, ly1;
+    lin_coord(X, w, x0, x1, lx0, lx1);
+    lin_coord(Y, h, y0, y1, ly0, ly1);
+    const float a = __builtin_fmaf(p(y0, x0), lx0, p(y0, x1) * lx1);
+    const float b = __builtin_fmaf(p(y1, x0), lx0, p(y1, x1) * lx1);
+    return __builtin_fmaf(a, ly0, b * ly1);
+}
+
 struct Args {
     const float *offs;     // guiding offsets: (N, ND*L, H, W) or, off_lowres, the stride-4 head output (N, ND*L, H/4, W/4)
     int off_lowres;
@@ -55,6 +68,11 @@ struct Args {
     const float *jitter;   // jitter-offset head (collect.py:127-138, :154-165, :210-214) or nullptr
     int jitter_mode;       // 0 none, 1 hi-res maps, 3 stride-4 maps sampled as bilinear x4
     float *limbs;          // (N, L, K, 13)
+    // flip-test folded into the sampling (PostProcess.flip_augment, decoder/factory.py:129-138; off_lowres, 2 components):
+    // offs holds (2N, 2L, H/4, W/4) = [images | mirrored images]; every tap reads (a + sign * b[limb_perm[l]][y][w-1-x]) / 2,
+    // sign = -1 for the x component, or a alone for the limbs of `reserve` -- the values og_flip_merge_f32 would have written
+    const int32_t *limb_perm = nullptr, *reserve = nullptr;
+    int flip_N = 0;
 };
 
 // Rows of limb type `l` of image `n` by one GROUP of lanes (a wave, or half a wave when K <= 32; `lane` = 0..GROUP-1
@@ -94,7 +112,23 @@ __device__ __forceinline__ void limb_rows(const Args &a, int n, int l, int lane,
     // The offset gather of the lane's FIRST from-candidate (two dependent round trips: candidate index, then the offset
     // taps in a tensor that is cold by now) is issued before the to-candidates are staged, so the two latencies overlap.
     auto gather_offsets = [&](int64_t id, int yi, int xi, float (&o4)[ND]) {   // offset at the ORIGINAL flat index (collect.py:143-147)
-        if (off_lowres) {
+        if (off_lowres && a.flip_N > 0) {
+            const int h4 = H / 4, w4 = W / 4;
+            const size_t hw4 = (size_t)h4 * w4;
+            const bool keep = a.reserve[l] != 0;
+            const float *pa = offs + ((size_t)n * ND * L + ND * l) * hw4;
+            const float *pb = offs + ((size_t)(n + a.flip_N) * ND * L + ND * a.limb_perm[l]) * hw4;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                const float sign = (c & 1) == 0 ? -1.f : 1.f;
+                const float *qa = pa + (size_t)c * hw4, *qb = pb + (size_t)c * hw4;
+                o4[c] = bilinear4_fn([&](int y, int x) {
+                    const float av = qa[(size_t)y * w4 + x];
+                    if (keep) return av;
+                    return (av + qb[(size_t)y * w4 + (w4 - 1 - x)] * sign) / 2.f;
+                }, h4, w4, yi, xi);
+            }
+        } else if (off_lowres) {
             const int h4 = H / 4, w4 = W / 4;
             const float *px = offs + ((size_t)n * ND * L + ND * l) * h4 * w4;
 #pragma unroll

@@ -63,10 +63,7 @@ struct ConvArgs {
     const unsigned short *x2;
     int Cin2, H2, W2, stride2, steps_main, steps_total, w_row;
     uint32_t magic_w, magic_h, magic_chunks;   // ceil(2^32 / d) for d = W, H, Cin/64 (0 when d == 1): q = umulhi(n, magic)
-    int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the halo kernels
-    int in_launch_reduce;        // 1: last-arriver reduction inside the launch; 0: conv_finish_kernel afterwards
-    int store_policy;            // halo kernel's output stores: 0 plain, 1 sc1 (write-through), 2 nt (OG_CONV_STORE)
-    int items;                   // halo kernel: work items (pixel tile x cout tile) per workgroup (OG_CONV_HALO_ITEMS)
+    int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the tiled kernels
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
 };
 
@@ -365,15 +362,6 @@ conv3x3_kernel(ConvArgs a)
     // vmcnt(0) -> barrier -> relaxed agent-scope ticket; the last arriver reads every slab with sc1 loads.
     // (An agent-scope release fence per workgroup instead writes back the XCD's whole L2 each time: measured
     // 3-10x slower here.)  Correct for any placement of a tile's splits over XCDs.
-    if (a.ksplit > 1 && !a.in_launch_reduce) {
-        // plain slab stores; conv_finish_kernel (next launch on the stream) sums them and runs the epilogue
-        f32x4 *slab = reinterpret_cast<f32x4 *>(a.partial) + ((size_t)blockIdx.x * a.ksplit + split) * (NT * MT * 256) + tid;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) slab[(n * MT + m) * 256] = acc[n][m];
-        return;
-    }
     if (a.ksplit > 1) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const int tile = blockIdx.x;
@@ -440,402 +428,23 @@ conv3x3_kernel(ConvArgs a)
     CONV_STAMP(5);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Halo-tiled direct convolution for the large levels (H, W multiples of 16; Cout multiple of 128).
-//
-// An im2col GEMM re-reads every input pixel nine times through L2; at the ~10 TB/s the L2->LDS path sustains,
-// a 128x128 GEMM tile (64 FLOP/B) tops out near 640 TFLOP/s.  Here one workgroup owns a 16x16-pixel x 128-cout
-// tile, stages the 18x18-pixel HALO of one 64-channel chunk once and serves all nine taps from it by shifting
-// the LDS read address (pixel index + dy*18 + dx): per chunk 41 KB of activations + 9 x 16 KB of weights for
-// 37.7 MFLOP (~200 FLOP/B), so the MFMA pipe, not L2, is the limit.
-//   8 waves = 4 (pixel rows x4) x 2 (64 couts); MFMA tile = 16 couts x one 16-pixel tile row; per (chunk, tap) step
-//   a wave issues 32 v_mfma_f32_16x16x32_bf16 against 16 ds_read_b128.
-//   LDS: halo double-buffered (2 x 48 KB), weight tile in a 4-ring (4 x 16 KB) = all 160 KiB: the next chunk's halo
-//   trickles in one DMA piece per step during taps 0..5, weights run three steps ahead, counted vmcnt(2).
-//   Every step is two barrier-separated phases, R (LDS fragment reads + DMA issue) and M (32 MFMA), and the two
-//   waves that share a SIMD run them in opposite order (ping-pong): with both in lockstep the MFMA pipe idled
-//   through every fragment fetch (0.88 us per step against 0.43 us of MFMA issue).
-//   The halo image is PADDED, not XOR-swizzled: 144 B per pixel (8 channel slots + 1 pad slot, the pad
-//   being part of the lane-linear DMA stream), so a tap is a compile-time byte offset ((dy*18+dx)*144) folded into
-//   the ds_read immediate and ONE address register serves all 72 pixel-fragment reads of a chunk; with the XOR
-//   swizzle hipcc kept 72 precomputed addresses live, hit the 256-VGPR cap of 2 waves/SIMD and spilled (scratch
-//   loads are vector-memory ops: every one of them drained the DMA queue with vmcnt(0)).  9 is odd, so 16 pixels
-//   of a tile row land on 16 different 16-B bank slots; the k-chunk offset between the two halves of a
-//   ds_read_b128 lane group leaves a 2-way conflict on 7 of 16 slots.  The weight tile keeps the XOR swizzle.
-// TW x TH = pixel tile (TW*TH a multiple of 16*WM), WM = waves along the pixels (8/WM along the 128 couts).
-// A 16-pixel MFMA column block is 16 consecutive pixels of the tile in row-major order (it may wrap over tile rows:
-// only the per-lane base address knows), so TW need not be a multiple of 16: 16x16 tiles serve 160x160 / 80x80,
-// full-width 40x4 tiles serve 40x40.
-template <int TW, int TH, int WM>
-__global__ void __launch_bounds__(512)
-conv3x3_halo_kernel(ConvArgs a)
-{
-    constexpr int BN = 128, WN = 8 / WM;
-    constexpr int kHaloW = TW + 2, kHaloPx = (TW + 2) * (TH + 2), kPitch = 144;
-    constexpr int NPA = (kHaloPx * 9 + 511) / 512;          // halo DMA pieces per thread (9 16-B slots per pixel)
-    constexpr int kABytes = NPA * 512 * 16, kBBytes = BN * 128;
-    constexpr int PW = BN * 8 / 512;                         // weight pieces per thread per step
-    constexpr int MT = TW * TH / 16 / WM, NT = 8 / WN;       // 16-pixel / 16-cout tiles per wave
-    static_assert(TW * TH % (16 * WM) == 0 && 8 % WM == 0 && NPA <= 6, "unsupported tile");
-    static_assert(2 * kABytes + 4 * kBBytes <= 160 * 1024, "LDS");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char *const bufA = lds, *const bufB = lds + 2 * kABytes;  // [A0 | A1 | B0..B3]
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // A workgroup takes a.items consecutive work items (item = pixel tile x 128-cout tile, cout tile fastest: the items of
-    // one workgroup share their halo); the first halo chunk and the first three weight tiles of item i+1 are fetched
-    // during the last chunk of item i, so only the first item of a workgroup pays the 6-9 us wait for its first data
-    // (with one workgroup per CU -- the kernel owns all of its LDS -- nothing else could run in that gap).
-    const int tiles_x = a.W / TW, tiles_y = a.H / TH, chunks = a.Cin >> 6;
-    const int n_items = a.N * tiles_y * tiles_x * a.n_tiles;
-    int item = blockIdx.x * a.items;
-    const int item_end = min(item + a.items, n_items);
-#define HALO_STAMP(i)                                                                                              \
-    do {                                                                                                            \
-        if (a.stamps && tid == 0) a.stamps[(size_t)item * 8 + (i)] = __builtin_amdgcn_s_memrealtime();              \
-    } while (0)
-#define HALO_CLOCK(i)                                                                                              \
-    do {                                                                                                            \
-        if (a.stamps && tid == 0) a.stamps[(size_t)item * 8 + (i)] = __builtin_readcyclecounter();                  \
-    } while (0)
-    HALO_STAMP(0);
-
-    // ---- loaders: byte offsets into x / w for buffer-addressed LDS-DMA; out-of-image halo pixels, the pad slot and
-    // pieces past the halo get an out-of-range offset and arrive as zeros
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.w), 0, a.w_bytes, 0x00020000);
-    uint32_t a_off[NPA];
-    struct Where { int n0, tx, ty, img; };
-    auto decode = [&](int it) {
-        Where wh;
-        wh.n0 = (it % a.n_tiles) * BN;
-        int t = it / a.n_tiles;
-        wh.tx = t % tiles_x;
-        t /= tiles_x;
-        wh.ty = t % tiles_y;
-        wh.img = t / tiles_y;
-        return wh;
-    };
-    auto set_a_off = [&](const Where &wh) {
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            const int p = tid + 512 * i, hp = p / 9, c = p - hp * 9;   // slot 8 of every pixel is padding
-            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
-            const int gy = wh.ty * TH - 1 + hy, gx = wh.tx * TW - 1 + hx;
-            const bool ok = c < 8 && hp < kHaloPx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            a_off[i] = ok ? (uint32_t)((((wh.img * a.H + gy) * a.W + gx) * a.Cin + c * 8) * 2) : kOobOffset;
-        }
-    };
-    uint32_t w_off_g[PW];   // within one 128-cout tile; the tile's base goes into the scalar offset
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int p = tid + 512 * i, r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
-        w_off_g[i] = (uint32_t)((r * 9 * a.Cin + c * 8) * 2);
-    }
-    const int piece = wave * 64 * 16;
-    auto issue_a = [&](int i, int q, int buf) {  // piece i of chunk q's halo
-        blds16(xr, a_off[i], q * 128, bufA + buf * kABytes + piece + i * 8192);
-    };
-    auto issue_b = [&](int w_n0, int q, int tap, int ring) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) blds16(wr, w_off_g[i], w_n0 + (tap * a.Cin + q * 64) * 2, bufB + ring * kBBytes + piece + i * 8192);
-    };
-
-    // ---- compute set-up
-    const int wm = wave / WN, wn = wave % WN;
-    const int fcol = lane & 15, fk = lane >> 4;
-    f32x4 acc[NT][MT];
-    int w_off[NT], w_sw[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int r = (wn * NT + n) * 16 + fcol;
-        w_off[n] = r * 128;
-        w_sw[n] = (r >> 1) & 7;
-    }
-    // byte offset of this lane's pixel of column block m at tap (0,0), k-chunk fk; taps and kh are immediates
-    int px_off[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int lp = (wm * MT + m) * 16 + fcol;
-        px_off[m] = ((lp / TW) * kHaloW + lp % TW) * kPitch + fk * 16;
-    }
-    const bool has_skip = a.skip != nullptr;
-    // residual operand of this lane's accumulators (global pixel index from the tile's origin)
-    auto load_skip = [&](const Where &wh, u16x4 (&sk)[NT][MT]) {
-        // a branch, not a select on the loaded value: the select made the wave wait for the loads where they are issued
-        // (in the hand-over epilogue: behind the first half's stores, 6 us)
-        if (has_skip) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int lp = (wm * MT + m) * 16 + fcol;
-                const size_t opx = (size_t)(wh.img * a.H + wh.ty * TH + lp / TW) * a.W + wh.tx * TW + lp % TW;
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    sk[n][m] = *reinterpret_cast<const u16x4 *>(a.skip + opx * a.Cout + wh.n0 + (wn * NT + n) * 16 + fk * 4);
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) sk[n][m] = (u16x4){0, 0, 0, 0};
-        }
-    };
-    auto init_acc = [&](const u16x4 (&sk)[NT][MT]) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[n][m] = (f32x4){bf2f(sk[n][m][0]), bf2f(sk[n][m][1]), bf2f(sk[n][m][2]), bf2f(sk[n][m][3])};
-    };
-
-    // ---- prologue: halo of chunk 0, weights of steps 0..2 of the first item
-    Where cur = decode(item);
-    set_a_off(cur);
-    int w_n0 = cur.n0 * 9 * a.Cin * 2;
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) issue_a(i, 0, 0);
-    issue_b(w_n0, 0, 0, 0);
-    issue_b(w_n0, 0, 1, 1);
-    issue_b(w_n0, 0, 2, 2);
-    HALO_STAMP(1);
-    wait_vm_lgkm0<2 * PW>();
-    // The residual operand initialises the accumulators (D = skip + sum of products) instead of being added in the
-    // epilogue: its 8-B-per-lane loads are in flight while the first stages land, and the main loop carries neither
-    // 32 extra registers nor extra vmcnt cases (prefetching it during the last taps stalled those steps).
-    {
-        u16x4 sk[NT][MT];
-        load_skip(cur, sk);
-        init_acc(sk);
-    }
-
-#ifndef OG_HALO_ABL
-#define OG_HALO_ABL 0   // timing ablations (wrong results): 1 no weight DMA, 2 no halo DMA, 4 fragments read once, 8 no MFMA
-#endif
-    bf16x8 pf[2][MT], wf[2][NT];
-    int qq = 0;   // chunks done by this workgroup: halo buffer = qq & 1, weight ring slot of a step = (qq + tap) & 3
-    for (;;) {
-        const bool has_next = item + 1 < item_end;
-        Where nxt = cur;
-        int w_n0_next = w_n0;
-        __builtin_amdgcn_s_barrier();
-        // Ping-pong: waves 4..7 (the second wave on every SIMD) run one phase behind waves 0..3, so that on each SIMD
-        // one wave is in its MFMA phase while the other fetches fragments from LDS.  They take one extra barrier here,
-        // waves 0..3 take it after the loop.
-        if (wave >= 4) __builtin_amdgcn_s_barrier();
-        HALO_STAMP(2);
-        HALO_CLOCK(6);
-
-        // Phase R(s): counted wait, DMA issue (weights of step s+3 into the 4-ring, one halo piece of the next chunk),
-        // 16 ds_read_b128, lgkmcnt(0) | barrier | phase M(s): 32 MFMA | barrier.
-        // DMA -> ds_read ordering: a wave's pieces of B(s+1) have landed at its wait in R(s) (everything but the two
-        // youngest pieces, B(s+2)); the late group's R(s) is one barrier before the early group's R(s+1).  Ring slot of
-        // B(s+3) = slot of B(s-1), last read in R(s-1) by both groups, at least one barrier (with lgkmcnt(0)) ago.
-        // The sequence runs on across the items of a workgroup: the "next chunk" of an item's last chunk is chunk 0 of
-        // the next item, B(s+3) of its last three steps are the next item's first weight tiles.
-#pragma unroll 1
-        for (int q = 0; q < chunks; ++q, ++qq) {
-            const unsigned char *hA = bufA + (qq & 1) * kABytes;
-            const bool last_chunk = q + 1 == chunks;
-            const bool more = !last_chunk || has_next;     // a chunk follows this one
-            if (last_chunk && has_next) {   // the halo of this item is complete: re-aim the loaders
-                nxt = decode(item + 1);
-                set_a_off(nxt);
-                w_n0_next = nxt.n0 * 9 * a.Cin * 2;
-            }
-            const int q_next = last_chunk ? 0 : q + 1;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // B(s+2) exists unless this is one of the last two steps
-                if (tap < 7 || more) wait_vm_lgkm0<PW>();
-                else wait_vm_lgkm0<0>();
-                if (!(OG_HALO_ABL & 2) && tap < NPA && more) issue_a(tap, q_next, (qq + 1) & 1);
-                const unsigned char *wB = bufB + ((qq + tap) & 3) * kBBytes;
-                const int shift = ((tap / 3) * kHaloW + tap % 3) * kPitch;
-                if (!(OG_HALO_ABL & 4) || (qq == 0 && tap == 0))
-#pragma unroll
-                for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        pf[kh][m] = *reinterpret_cast<const bf16x8 *>(hA + px_off[m] + shift + kh * 64);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        wf[kh][n] = *reinterpret_cast<const bf16x8 *>(wB + w_off[n] + (((fk + 4 * kh) ^ w_sw[n]) << 4));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                if (!(OG_HALO_ABL & 8)) {
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m)
-                                acc[n][m] = OG_LP_MFMA(wf[kh][n], pf[kh][m], acc[n][m]);
-                } else {
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(wf[kh][n]));
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(pf[kh][m]));
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-                {   // weight DMA behind the MFMA queue of this step (2 % faster in the network than issuing it in the R
-                    // phase; the halo piece stays there: moving both costs 12 %)
-                    const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9;
-                    const bool wraps = tap + 3 >= 9;
-                    if (!(OG_HALO_ABL & 1) && (!wraps || more))
-                        issue_b(wraps && last_chunk ? w_n0_next : w_n0, wraps ? q_next : q, t3, (qq + tap + 3) & 3);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (wave < 4) __builtin_amdgcn_s_barrier();
-
-        HALO_CLOCK(7);
-        HALO_STAMP(3);
-        // ---- epilogue: bias + ReLU + the one rounding happen in the accumulator layout (the residual is already in);
-        // the bf16 tile then goes through LDS ([tile pixels][128 couts], pitch 272 B: conflict-free ds_write_b64) so that
-        // global stores are 16 B per lane, 256 B contiguous per pixel.  (Storing the accumulator layout straight out
-        // -- 8 B per lane at a 512-B stride -- took 12 us of a 47 us workgroup; staging fp32 and adding the residual
-        // after it 8 us.)  Last item of the workgroup: the whole tile at once, all of the LDS is free.  Otherwise the
-        // next item's first halo chunk and weight tiles are already in LDS: the tile goes out in two halves through the
-        // halo buffer of the chunk just finished, and the next item's residual loads are issued as soon as a wave's
-        // accumulators are in LDS, so they fly under the stores.
-        constexpr int kOPitch = BN * 2 + 16, kTilePx = TW * TH;
-        constexpr int kPerPx = BN / 8;
-        static_assert(kTilePx * kOPitch <= 2 * kABytes + 4 * kBBytes, "output staging must fit the LDS of the main loop");
-        static_assert(kTilePx / 2 * kOPitch <= kABytes && kTilePx % 2 == 0 && (kTilePx / 2) % 16 == 0, "half-tile staging must fit one halo buffer");
-        const size_t tile_px = (size_t)(cur.img * a.H + cur.ty * TH) * a.W + cur.tx * TW;
-        // bias in registers before the first store is issued: loads and stores share vmcnt, a bias load behind the first
-        // half's stores waited for them to drain (10 us per hand-over instead of 3)
-        f32x4 bias_r[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bias_r[n] = *reinterpret_cast<const f32x4 *>(a.bias + cur.n0 + (wn * NT + n) * 16 + fk * 4);
-        auto stage = [&](unsigned char *base, int px0, int px1) {   // this wave's pixels in [px0, px1) -> LDS rows from base
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int px = (wm * MT + m) * 16 + fcol;
-                if ((wm * MT + m) * 16 < px0 || (wm * MT + m) * 16 >= px1) continue;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int cl = (wn * NT + n) * 16 + fk * 4;
-                    f32x4 v = acc[n][m] + bias_r[n];
-                    u16x4 o;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) o[jj] = f2bf(a.relu ? fmaxf(v[jj], 0.f) : v[jj]);
-                    *reinterpret_cast<u16x4 *>(base + (px - px0) * kOPitch + cl * 2) = o;
-                }
-            }
-        };
-        auto store_rows = [&](const unsigned char *base, int px0, int npx) {
-            const int groups = npx * kPerPx;
-            for (int g = tid; g < groups; g += 512) {
-                const int px = px0 + g / kPerPx, cg = g % kPerPx;
-                const size_t off = (tile_px + (size_t)(px / TW) * a.W + (px % TW)) * a.Cout + cur.n0 + cg * 8;
-                const u16x8 v = *reinterpret_cast<const u16x8 *>(base + (px - px0) * kOPitch + cg * 16);
-                // Write-through keeps the Infinity Cache free of DIRTY activations (OG_CONV_STORE; measured: no difference)
-                if (a.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a.out + off), "v"(v) : "memory");
-                else if (a.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(a.out + off), "v"(v) : "memory");
-                else *reinterpret_cast<u16x8 *>(a.out + off) = v;
-            }
-        };
-        if (!has_next) {
-            __syncthreads();  // all waves are done reading the last stage
-            stage(lds, 0, kTilePx);
-            __syncthreads();
-            store_rows(lds, 0, kTilePx);
-            HALO_STAMP(5);
-            break;
-        }
-        unsigned char *const stg = bufA + ((qq - 1) & 1) * kABytes;   // qq has moved on: the finished chunk's buffer
-        u16x4 sk[NT][MT];
-        // raw barriers with explicit LDS waits: __syncthreads() also drains vmcnt, i.e. waits for the previous half's
-        // global stores to be acknowledged (8.8 us per hand-over instead of 3)
-        auto lds_barrier = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        lds_barrier();   // all waves are done reading the last stage
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            stage(stg, h * (kTilePx / 2), (h + 1) * (kTilePx / 2));
-            if (h == 1) load_skip(nxt, sk);   // every accumulator of the workgroup is in LDS or already stored
-            lds_barrier();
-#ifdef OG_HALO_EPI_STAMPS
-            if (h == 0) HALO_STAMP(4); else HALO_STAMP(7);
-#endif
-            store_rows(stg, h * (kTilePx / 2), kTilePx / 2);
-            lds_barrier();
-#ifdef OG_HALO_EPI_STAMPS
-            if (h == 0) HALO_STAMP(6);
-#endif
-        }
-        HALO_STAMP(5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores and loads share the counter: drain, then start the steady state afresh
-        init_acc(sk);
-        ++item;
-        cur = nxt;
-        w_n0 = w_n0_next;
-    }
-#undef HALO_STAMP
-#undef HALO_CLOCK
-}
-
-// Second launch of the two-launch form: one workgroup per output tile sums the ksplit slabs (coalesced 16 B per
-// lane, all loads independent) and runs the epilogue with the thread mapping of the conv kernel.
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-conv_finish_kernel(ConvArgs a)
-{
-    constexpr int MT = BM / 32, NT = BN / 32;
-    const int tid = threadIdx.x, tile = blockIdx.x;
-    const f32x4 *slab = reinterpret_cast<const f32x4 *>(a.partial) + (size_t)tile * a.ksplit * (NT * MT * 256) + tid;
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = slab[(n * MT + m) * 256];
-    for (int sp = 1; sp < a.ksplit; ++sp) {
-        const f32x4 *o = slab + (size_t)sp * (NT * MT * 256);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] += o[(n * MT + m) * 256];
-    }
-    epilogue_store<BM, BN>(acc, a, (tile / a.n_tiles) * BM, (tile % a.n_tiles) * BN, tid >> 6, tid & 63);
-}
-
 struct Plan {
-    int bm, bn, stages, ksplit, steps_per_split, m_tiles, n_tiles, in_launch;
+    int bm, bn, stages, ksplit, steps_per_split, m_tiles, n_tiles;
 };
 
-// Tile and K split.  Measured inside the network (bs8, tools/bb_bench.py, whole-forward ms): 64-wide tiles with
-// ~6 K splits 10.82, 64/3 10.89, shape-dependent 128-wide tiles 11.15, 128/3 11.85, no split 11.82; MIOpen 11.59.
+// Tile and K split.  Measured inside the network (bs8, whole-forward ms, round 1): 64-wide tiles with ~6 K splits 10.82, 64/3
+// 10.89, shape-dependent 128-wide tiles 11.15, 128/3 11.85, no split 11.82; per layer (us, conv + reduction) 20x20 with 2/3/6/9
+// splits = 34.9/31.4/36.2/41.1, 10x10 = 19.5/16.2/15.6/18.5, 5x5 = 22.5/17.4/12.7/12.7.  At 20x20 (M >= 2048) a 128 x 64 tile
+// (6 fragment reads per 16 MFMA instead of 8 per 8) with 3 splits and 3 stages: 24.7 us against 29.0 for 64 x 64 x 3.  The
+// reduction runs inside the launch (last arriver); the plan sweeps of rounds 1-3 are in EXPERIMENTS.md.
 bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps = 0)
 {
     const int steps = taps * Cin / 64 + extra_steps;
-    const char *e = getenv("OG_CONV_PLAN");  // "bm,ksplit,stages" override for tuning
-    int bm = 64, force_split = 0, force_stages = 0;
-    if (e) sscanf(e, "%d,%d,%d", &bm, &force_split, &force_stages);
-    if (bm != 64 && bm != 128) return false;
-    if (bm == 128 && Cout % 128 != 0) return false;
-    p.bm = p.bn = bm;
-    p.stages = bm == 128 ? 3 : 4;
-    if (steps < 3) p.stages = 3;  // 1x1 convolutions with Cin = 128: two K steps
-    if (force_stages == 4 || force_stages == 3 || ((force_stages == 8 || force_stages == 2) && bm == 64)) p.stages = force_stages;
-    p.m_tiles = (int)((M + bm - 1) / bm);
-    p.n_tiles = Cout / bm;
-    // per layer inside the network (rocprofv3, conv + finish, us): 20x20 ks 2/3/6/9 = 34.9/31.4/36.2/41.1,
-    // 10x10 = 19.5/16.2/15.6/18.5, 5x5 = 22.5/17.4/12.7/12.7
-    // enough tiles to fill the chip several times over (the stride-2 / 1x1 layers of the large levels): no K split
+    p.bm = p.bn = 64;
+    p.stages = steps < 3 ? 3 : 4;      // 1x1 convolutions with Cin = 128: two K steps
+    p.m_tiles = (int)((M + 63) / 64);
+    p.n_tiles = Cout / 64;
+    // enough tiles to fill the chip several times over (stride-2 / 1x1 layers of larger levels): no K split
     const int max_ks = (long)p.m_tiles * p.n_tiles >= 1024 ? 1 : M >= 2048 ? 3 : 6;
     int best = 1;
     for (int ks = 2; ks <= max_ks; ++ks)
@@ -845,35 +454,20 @@ bool make_plan(long M, int Cin, int Cout, Plan &p, int taps = 9, int extra_steps
             const int sps = (steps + ks - 1) / ks, last = steps - (ks - 1) * sps;
             if (sps >= 4 && last >= p.stages - 1 && last >= 1) best = ks;
         }
-    if (M >= 2048 && max_ks > 1 && !e) {   // 20x20 at bs8 (tuning knob: OG_CONV_MID_PLAN="bm,ksplit,stages")
-        // default: 128 x 64 tiles (6 fragment reads per 16 MFMA instead of 8 per 8), 3 K splits, 3 stages = 450 workgroups of
-        // 72 KiB at batch 8: 24.7 us against 29.0 for 64 x 64 x 3 splits (tools/mid_plan_sweep.sh)
-        int mb = 128, mk = 3, ms = 3, mn = 64;      // "bm,ksplit,stages[,bn]": bn 64 with bm 128 = the rectangular tile
-        if (const char *mp = getenv("OG_CONV_MID_PLAN")) sscanf(mp, "%d,%d,%d,%d", &mb, &mk, &ms, &mn);
-        const bool rect = mb == 128 && mn == 64;
-        const bool bm_ok = mb == 64 || rect || (mb == 128 && Cout % 128 == 0);
-        if (bm_ok && mk >= 1 && mk <= 3 && (ms == 3 || ms == 4 || (ms == 2 && mb == 64)) && (steps + mk - 1) / mk >= 4) {
-            const int sps = (steps + mk - 1) / mk, last = steps - (mk - 1) * sps;
-            if (last >= ms - 1 && (steps % mk == 0 || extra_steps)) {
-                best = mk;
-                p.stages = ms;
-                p.bm = p.bn = mb;
-                if (rect) p.bn = 64;
-                p.m_tiles = (int)((M + mb - 1) / mb);
-                p.n_tiles = Cout / p.bn;
-            }
+    if (M >= 2048 && max_ks > 1) {   // 20x20 at bs8: the rectangular tile
+        const int mk = 3, ms = 3, sps = (steps + mk - 1) / mk, last = steps - (mk - 1) * sps;
+        if (sps >= 4 && last >= ms - 1 && (steps % mk == 0 || extra_steps)) {
+            best = mk;
+            p.stages = ms;
+            p.bm = 128;
+            p.bn = 64;
+            p.m_tiles = (int)((M + 127) / 128);
+            p.n_tiles = Cout / 64;
         }
     }
-    if (force_split > 0 && steps % force_split == 0 && steps / force_split >= p.stages - 1) best = force_split;
     if (steps < p.stages - 1) return false;
     p.ksplit = best;
     p.steps_per_split = (steps + best - 1) / best;
-    // In-launch reduction (last arriver, one batch of sc1 loads) vs a finish kernel, per layer inside the network:
-    // 20x20 30.1 vs 32.0 us, 10x10 14.4 vs 15.9, 5x5 13.4 vs 13.1.  (With 128-wide tiles and 6 splits the in-launch
-    // form lost at 20x20, 39.9 vs 34.2: slab bytes per last arriver decide.)
-    p.in_launch = 1;
-    if (const char *r = getenv("OG_CONV_REDUCE")) p.in_launch = atoi(r);
-    if (p.bm != p.bn) p.in_launch = 1;      // the finish kernel exists for the square tiles only
     return true;
 }
 
@@ -890,16 +484,6 @@ size_t ws_layout(const Plan &p, size_t *counters_off, size_t *slabs_off)
 }
 
 static unsigned long long *g_stamps = nullptr;
-
-// Large levels go to the halo-tiled kernel: 1 = 16x16 tiles (H, W multiples of 16), 2 = 40x4 full-width tiles
-// (W == 40, H multiple of 4), 0 = not applicable.  OG_CONV_HALO=0 disables, =1 forces it wherever the shape allows.
-int halo_kind(long M, int H, int W, int Cin, int Cout)
-{
-    if (Cout % 128 || Cin % 64) return 0;
-    const int kind = (H % 16 == 0 && W % 16 == 0) ? 1 : (W == 40 && H % 4 == 0) ? 2 : 0;
-    if (const char *e = getenv("OG_CONV_HALO")) return atoi(e) != 0 ? kind : 0;
-    return M >= 8192 ? kind : 0;
-}
 
 #include "conv3x3_tiled.inc"
 
@@ -921,15 +505,13 @@ OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
 }
 
 
-// Exact requirement for one layer: the halo-tiled kernel of the large levels needs no scratch beyond the fixed
-// head of the layout (the split-K slabs of og_conv3x3_workspace_bytes would be hundreds of MB there).
+// Exact requirement for one layer.
 OG_API size_t og_conv2d_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride)
 {
     if (N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return 0;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     const int H = conv_out_dim(Hin, ksize, stride), W = conv_out_dim(Win, ksize, stride);
     const long M = (long)N * H * W;
-    if (ksize == 3 && stride == 1 && halo_kind(M, H, W, Cin, Cout)) return kZeroPageBytes + kMaxTiles * sizeof(int);
     Plan p;
     if (!make_plan(M, Cin, Cout, p, ksize * ksize)) return 0;
     return ws_layout(p, nullptr, nullptr);
@@ -980,39 +562,6 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
                    "%s: projection input %dx%d / stride %d does not give the %dx%d output", name, pj.H2, pj.W2, pj.stride2, H, W);
         OG_REQUIRE((long)N * pj.H2 * pj.W2 * pj.Cin2 < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
     }
-    if (const int kind = (ksize == 3 && stride == 1 && !pj.x2) ? halo_kind(M, H, W, Cin, Cout) : 0) {
-        ConvArgs h = {};
-        h.x = (const unsigned short *)x; h.w = (const unsigned short *)w; h.bias = bias;
-        h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out; h.zero = (const unsigned short *)workspace;
-        h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;
-        { static const int policy = getenv("OG_CONV_STORE") ? atoi(getenv("OG_CONV_STORE")) : 0; h.store_policy = policy; }
-        h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
-        // OG_CONV_HALO_ITEMS = k: k work items per workgroup where the grid stays >= 2 x the CUs; -k: always (tests)
-        static const int items_env = getenv("OG_CONV_HALO_ITEMS") ? atoi(getenv("OG_CONV_HALO_ITEMS")) : 1;
-        h.items = items_env < 0 ? -items_env : items_env < 1 ? 1 : items_env;
-        const bool items_forced = items_env < 0;
-        h.stamps = g_stamps;
-        h.x_bytes = (int)(M * Cin * 2);
-        h.w_bytes = Cout * 9 * Cin * 2;
-        OG_REQUIRE(workspace_bytes >= kZeroPageBytes, OG_ENOSPC, "%s: workspace too small", name);
-#define HALO_LAUNCH(TW_, TH_, WM_)                                                                              \
-    do {                                                                                                        \
-        constexpr int npa_ = ((TW_ + 2) * (TH_ + 2) * 9 + 511) / 512, lds_ = 2 * npa_ * 8192 + 4 * 128 * 128;   \
-        static OgAttrOnce attr_;                                                                                \
-        if (attr_.need())                                                                                       \
-            (void)hipFuncSetAttribute((const void *)conv3x3_halo_kernel<TW_, TH_, WM_>,                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
-        const long items_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles;                                        \
-        if (!items_forced && items_ < 1024 * (long)h.items / 2) h.items = 1;                                      \
-        const long blocks_ = (items_ + h.items - 1) / h.items;                                                  \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<TW_, TH_, WM_>), dim3((unsigned)blocks_), dim3(512), lds_, st, h); \
-    } while (0)
-        if (kind == 1) HALO_LAUNCH(16, 16, 4);
-        else HALO_LAUNCH(40, 4, 2);
-#undef HALO_LAUNCH
-        OG_LAUNCH_CHECK(name);
-        return OG_OK;
-    }
     Plan p;
     OG_REQUIRE(make_plan(M, Cin, Cout, p, taps, pj.x2 ? pj.Cin2 / 64 : 0), OG_EUNSUPPORTED, "%s: no tile plan", name);
     OG_REQUIRE((size_t)p.m_tiles * p.n_tiles <= kMaxTiles, OG_EUNSUPPORTED, "%s: too many tiles", name);
@@ -1040,37 +589,21 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); };
     a.magic_w = magic((uint32_t)W); a.magic_h = magic((uint32_t)H); a.magic_chunks = magic((uint32_t)(Cin / 64));
     a.stamps = g_stamps;
-    a.in_launch_reduce = p.in_launch;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
     const dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)p.ksplit);
-#define CONV_LAUNCH(BM_, ST_)                                                                                   \
+#define CONV_LAUNCH(BM_, BN_, ST_)                                                                              \
     do {                                                                                                        \
-        constexpr int lds_ = ST_ * 2 * BM_ * 128;                                                               \
+        constexpr int lds_ = ST_ * (BM_ + BN_) * 128;                                                           \
         static OgAttrOnce attr_;                                                                                \
         if (attr_.need())                                                                                       \
-            (void)hipFuncSetAttribute((const void *)conv3x3_kernel<BM_, BM_, ST_>,                              \
+            (void)hipFuncSetAttribute((const void *)conv3x3_kernel<BM_, BN_, ST_>,                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                        \
-        hipLaunchKernelGGL((conv3x3_kernel<BM_, BM_, ST_>), grid, dim3(256), lds_, st, a);                      \
+        hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_, ST_>), grid, dim3(256), lds_, st, a);                      \
     } while (0)
-    if (p.bm == 128 && p.bn == 64) {
-        constexpr int lds_ = 3 * (128 + 64) * 128;
-        static OgAttrOnce attr_;
-        if (attr_.need())
-            (void)hipFuncSetAttribute((const void *)conv3x3_kernel<128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
-        hipLaunchKernelGGL((conv3x3_kernel<128, 64, 3>), grid, dim3(256), lds_, st, a);
-    } else if (p.bm == 128 && p.stages == 4) CONV_LAUNCH(128, 4);
-    else if (p.bm == 128) CONV_LAUNCH(128, 3);
-    else if (p.stages == 8) CONV_LAUNCH(64, 8);
-    else if (p.stages == 3) CONV_LAUNCH(64, 3);
-    else if (p.stages == 2) CONV_LAUNCH(64, 2);
-    else CONV_LAUNCH(64, 4);
+    if (p.bm == 128) CONV_LAUNCH(128, 64, 3);
+    else if (p.stages == 3) CONV_LAUNCH(64, 64, 3);
+    else CONV_LAUNCH(64, 64, 4);
 #undef CONV_LAUNCH
-    if (p.ksplit > 1 && !p.in_launch) {
-        OG_LAUNCH_CHECK(name);
-        const dim3 fgrid((unsigned)(p.m_tiles * p.n_tiles));
-        if (p.bm == 128) hipLaunchKernelGGL((conv_finish_kernel<128, 128>), fgrid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_finish_kernel<64, 64>), fgrid, dim3(256), 0, st, a);
-    }
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -1175,62 +708,23 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
         h.counters = (int *)((char *)workspace + kZeroPageBytes);
         h.partial = (float *)((char *)workspace + kZeroPageBytes + kMaxTiles * sizeof(int));
     }
-#define TILED_LAUNCH(TW_, TH_, WM_, VAR_) TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, 4)
-#define TILED_LAUNCH_NW(TW_, TH_, WM_, VAR_, NW_)                                                                     \
+#define TILED_LAUNCH(TW_, TH_, WM_, VAR_)                                                                             \
     do {                                                                                                              \
         constexpr int halo_ = ((TW_ + 2) * (TH_ + 2) * 5 * 16 + 1023) / 1024 * 1024;                                  \
-        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024 + lds_extra;                                                 \
+        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024;                                                             \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
-            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>,                   \
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, 4>,                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles * h.ksplit;                                  \
-        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, NW_>), dim3((unsigned)blocks_), dim3(64 * NW_), lds_, st, h); \
+        hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, 4>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
     } while (0)
-    // OG_TILED_LDS_EXTRA (experiment): bytes of LDS requested on top of the kernel's own: 16384 leaves one workgroup per CU
-    static const int lds_extra = getenv("OG_TILED_LDS_EXTRA") ? atoi(getenv("OG_TILED_LDS_EXTRA")) : 0;
-    // OG_TILED_VAR (tuning phase): bits 0-3 = the kernel's VAR switches, 16 = 2 x 2 waves (128 pixels x 64 couts each)
-    const char *ve = getenv("OG_TILED_VAR");
-    const int var = ve ? atoi(ve) : 0;
-    if (kind == 1) {
-        switch (var) {
-        case 0: TILED_LAUNCH(16, 16, 4, 0); break;
-        case 2: TILED_LAUNCH(16, 16, 4, 2); break;
-        case 8: TILED_LAUNCH(16, 16, 4, 8); break;
-        case 10: TILED_LAUNCH(16, 16, 4, 10); break;
-        case 64: TILED_LAUNCH_NW(16, 16, 4, 0, 8); break;    // 8 waves: 64 x 64 outputs per wave, four waves per SIMD
-        case 66: TILED_LAUNCH_NW(16, 16, 4, 2, 8); break;
-#ifdef OG_TILED_ABLATIONS     // timing-only builds (wrong results): tools/build_variants.sh conv3x3.hip abl "-DOG_TILED_ABLATIONS"
-        case 26: TILED_LAUNCH(16, 16, 4, 26); break;     // 10 + no DMA
-        case 42: TILED_LAUNCH(16, 16, 4, 42); break;     // 10 + fragments read once
-        case 74: TILED_LAUNCH(16, 16, 4, 74); break;     // 10 + no barrier
-        case 58: TILED_LAUNCH(16, 16, 4, 58); break;     // 10 + no DMA + fragments read once
-        case 122: TILED_LAUNCH(16, 16, 4, 122); break;   // MFMA only
-        case 138: TILED_LAUNCH(16, 16, 4, 138); break;   // 10 + waits relaxed by one step
-        case 258: TILED_LAUNCH(16, 16, 4, 258); break;   // 2 + weights always from the same two stages (L1 hits)
-        case 770: TILED_LAUNCH(16, 16, 4, 770); break;   // 2 + that + halo always chunk 0
-        case 18: TILED_LAUNCH(16, 16, 4, 18); break;     // 2 + no DMA
-#endif
-        // default: DMA issue behind the fragment reads.  (+ 8, the weight-fragment prefetch, is 1-3 % faster on the layer alone and
-        // no faster inside the network, for 14 more registers)
-        default: TILED_LAUNCH(16, 16, 4, 2); break;
-        }
-    } else if (kind == 3) {
-        TILED_LAUNCH(20, 4, 1, 2);
-    } else {
-        // OG_TILED_VAR40 (tuning phase): the 40-wide level: 0 / 2 = 40 x 4 tiles (160 pixels), 32 / 34 = 20 x 4 tiles (80 pixels: twice
-        // the workgroups), +2 = DMA issue behind the reads
-        const char *ve40 = getenv("OG_TILED_VAR40");
-        switch (ve40 ? atoi(ve40) : -1) {
-        case 32: TILED_LAUNCH(20, 4, 1, 0); break;
-        case 34: TILED_LAUNCH(20, 4, 1, 2); break;
-        case 0: TILED_LAUNCH(40, 4, 2, 0); break;
-        // default 40 x 4: the 20 x 4 tiles are 10 % faster on a layer alone (480 workgroups instead of 240), not inside the network
-        default: TILED_LAUNCH(40, 4, 2, 2); break;
-        }
-    }
+    // VAR 2 = LDS-DMA issue behind the fragment reads (measured best; the other tuning variants -- weight-fragment prefetch,
+    // 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only ablations -- are described in EXPERIMENTS.md)
+    if (kind == 1) TILED_LAUNCH(16, 16, 4, 2);
+    else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
+    else TILED_LAUNCH(40, 4, 2, 2);
 #undef TILED_LAUNCH
-#undef TILED_LAUNCH_NW
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -1279,8 +773,6 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
     h.x_bytes = (int)(Min * Cin * 2);
     h.w_bytes = Cout * 9 * Cin * 2;
     constexpr int lds_ = 3 * 128 * 64 + 3 * 3 * 4096;
-    const char *ve = getenv("OG_TILED_S2_VAR");
-    const int var = ve ? atoi(ve) : 0;
 #define S2_LAUNCH(TW_, TH_, WM_, VAR_)                                                                                \
     do {                                                                                                              \
         static OgAttrOnce attr_;                                                                                      \
@@ -1292,7 +784,6 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
                            (hipStream_t)stream, h);                                                                   \
     } while (0)
     if (kind == 2) S2_LAUNCH(40, 2, 1, 2);
-    else if (ve && var == 0) S2_LAUNCH(16, 8, 2, 0);
     else S2_LAUNCH(16, 8, 2, 2);       // DMA issue behind the fragment reads: measured 1-4 % faster
 #undef S2_LAUNCH
     OG_LAUNCH_CHECK(name);

@@ -520,27 +520,13 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
     }
 }
 
-// TAIL (og_generate_limbs_f32): the rest of generate_limbs inside this launch, by last arrivers --
-//   the band that finishes a plane LAST merges the plane's band lists and writes its (k) list;
-//   the plane that completes a limb type's pair of joint planes LAST pairs that limb type (one wave per limb type);
-//   the plane that finishes last of all validates the workspace for the next call.
-// Hand-offs: sc1 stores, s_waitcnt vmcnt(0), barrier, one relaxed agent-scope atomic add whose returned value names the
-// last arriver, which reads with sc1 loads; every ticket is back at zero when the launch ends.  Nobody waits for anybody.
-struct TailArgs {
-    int *tickets;            // [planes] plane tickets | [N * L] limb tickets | [1] planes done -- all zero between launches
-    float *out_scores;       // (planes, k)
-    int64_t *out_inds;
-    og_collect::Args ca;
-    int nd, t_sub, planes;
-};
-
-template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false, bool TAIL = false>
+template <int VEC, bool NMS_MODE, int PF, int ABL = 0, bool FUSED = false>
 // (amdgpu_waves_per_eu: <= 96 VGPRs -- at bs8 640x640 all 1 088 workgroups must be resident together, 5 per CU)
 __global__ void __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(5)))
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                  int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
                  int H, int W, int k, int cap, BandMap bm, int max_bands, int panel_strips, int total, int padded, int helper,
-                 int wl, TailArgs tl)
+                 int wl)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
     // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
@@ -751,7 +737,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     // per-wave top-k, then merge the waves' lists by rank counting
     seg.compact(k);
     BAND_STAMP(3);
-    if (!TAIL && wl > 1) {
+    if (wl > 1) {
         // one list per streaming wave (wl = streaming waves per band): no workgroup barrier, no cross-wave ranking here --
         // the merge launch ranks the plane's nbands * wl sorted lists anyway.  The helper wave has no list.
         if (wave < nstream) {
@@ -771,124 +757,16 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     int total_keys = 0;
     for (int w = 0; w < nwaves; ++w) total_keys += s_cnt[w];
     uint64_t *out = band_keys + (size_t)wid * k;
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t okr = __builtin_amdgcn_make_buffer_rsrc(out, 0, k * 8, 0x00020000);
     for (int t = threadIdx.x; t < total_keys; t += blockDim.x) {
         int w = 0, o = t;
         while (o >= s_cnt[w]) { o -= s_cnt[w]; ++w; }
         const uint64_t key = smem[(size_t)s_slot[w] * cap + o];
         int rank = 0;
         for (int w2 = 0; w2 < nwaves; ++w2) rank += og_count_greater(smem + (size_t)s_slot[w2] * cap, s_cnt[w2], key);
-        if (rank < k) {
-            if constexpr (TAIL) {
-                u32x2 v;
-                v.x = (uint32_t)key;
-                v.y = (uint32_t)(key >> 32);
-                __builtin_amdgcn_raw_buffer_store_b64(v, okr, rank * 8, 0, 16);   // sc1: write-through
-            } else {
-                out[rank] = key;
-            }
-        }
+        if (rank < k) out[rank] = key;
     }
-    for (int t = min(total_keys, k) + threadIdx.x; t < k; t += blockDim.x) {   // the list is zero-padded to k keys
-        if constexpr (TAIL) {
-            u32x2 v;
-            v.x = 0u;
-            v.y = 0u;
-            __builtin_amdgcn_raw_buffer_store_b64(v, okr, t * 8, 0, 16);
-        } else {
-            out[t] = 0ull;
-        }
-    }
+    for (int t = min(total_keys, k) + threadIdx.x; t < k; t += blockDim.x) out[t] = 0ull;   // the list is zero-padded to k keys
     BAND_STAMP(4);
-    if constexpr (TAIL) {
-        const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-        int *s_flag = s_cnt;   // the per-wave counts are not needed any more
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(tl.tickets + plane, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == nbands - 1;
-            if (last) __hip_atomic_store(tl.tickets + plane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-            s_flag[0] = last;
-        }
-        __syncthreads();
-        if (!s_flag[0]) return;
-        // ---- this band finished the plane: merge its band lists (LDS of the stream is free now) ----
-        // LDS of the tail (band_tail_lds_bytes): [all | flt] merge buffers, bound, count, to-do list, per wave 4 lists + scratch
-        const int n_all = nbands * k, Kp = (k + 3) & ~3;
-        uint64_t *all = smem, *flt = smem + n_all;
-        uint64_t *s_bound = smem + 2 * (size_t)n_all;
-        int *s_nf = reinterpret_cast<int *>(s_bound + 1);
-        int *s_todo = s_nf + 1;                   // [0] count, [1..] limb types this workgroup pairs
-        __syncthreads();                          // s_flag read by everyone before the region is reused
-        if (hist_all)   // the plane's slot table is no longer read: leave it clean for the next call
-            for (int i = tid; i < max_bands; i += nthr) hist_all[(size_t)plane * max_bands + i] = 0;
-        float *os = tl.out_scores + (size_t)plane * k;
-        int64_t *oi = tl.out_inds + (size_t)plane * k;
-        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(os, 0, k * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(oi, 0, k * 8, 0x00020000);
-        merge_plane<true, false, true>(band_keys + (size_t)(wid - band) * k, all, flt, s_bound,
-                                       s_nf, tid, nthr, in + (size_t)plane * H * W, H, W, k, nbands, tl.t_sub,
-                                       [&](int rank, float v, long idx) {
-                                           u32x2 w;
-                                           w.x = (uint32_t)idx;
-                                           w.y = 0u;   // flat indices are < 2^27
-                                           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), sr, rank * 4, 0, 16);
-                                           __builtin_amdgcn_raw_buffer_store_b64(w, ir, rank * 8, 0, 16);
-                                       });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) s_todo[0] = 0;
-        __syncthreads();
-        // ---- limb types that use this plane: the second of their two planes pairs them ----
-        const int C = tl.ca.C, L = tl.ca.L, n = plane / C, c = plane - n * C;
-        int *limb_tickets = tl.tickets + tl.planes + n * L;
-        for (int l = tid; l < L; l += nthr) {
-            const int hit = (tl.ca.jf[l] == c) + (tl.ca.jt[l] == c);
-            if (hit) {
-                const int old = __hip_atomic_fetch_add(limb_tickets + l, hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + hit == 2) {
-                    __hip_atomic_store(limb_tickets + l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_todo[1 + atomicAdd(&s_todo[0], 1)] = l;
-                }
-            }
-        }
-        if (tid == 0) {   // the last plane of all: every slot table is clean, the workspace is valid for this geometry again
-            int *done = tl.tickets + tl.planes + (tl.planes / C) * L;
-            const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == tl.planes - 1) {
-                __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *ws_magic = hist_all ? magic : 0ull;
-            }
-        }
-        __syncthreads();
-        const int ntodo = s_todo[0];
-        // one wave per limb type: both (k) lists by sc1 loads into the wave's LDS scratch, then collect_body.h
-        float *wsc = reinterpret_cast<float *>(smem) + ((4 * n_all + 2 + 2 + L + 1 + 3) & ~3) + (size_t)wave * 8 * Kp;   // 16-byte aligned
-        for (int t = wave; t < ntodo; t += nwaves) {
-            const int l = s_todo[1 + t];
-            const int pf = n * C + tl.ca.jf[l], pt = n * C + tl.ca.jt[l];
-            float *lsf = wsc, *lst = wsc + Kp;
-            int *lif = reinterpret_cast<int *>(wsc + 2 * Kp), *lit = lif + Kp;
-            float *sm = wsc + 4 * Kp;
-            const __amdgpu_buffer_rsrc_t s_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_scores, 0, tl.planes * k * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t i_all = __builtin_amdgcn_make_buffer_rsrc(tl.out_inds, 0, tl.planes * k * 8, 0x00020000);
-            for (int i = lane; i < k; i += 64) {
-                lsf[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_all, (pf * k + i) * 4, 0, 16));
-                lst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_all, (pt * k + i) * 4, 0, 16));
-                lif[i] = __builtin_amdgcn_raw_buffer_load_b32(i_all, (pf * k + i) * 8, 0, 16);
-                lit[i] = __builtin_amdgcn_raw_buffer_load_b32(i_all, (pt * k + i) * 8, 0, 16);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (tl.nd == 2) og_collect::limb_rows<2, int>(tl.ca, n, l, lane, lsf, lif, lst, lit, sm);
-            else og_collect::limb_rows<4, int>(tl.ca, n, l, lane, lsf, lif, lst, lit, sm);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
 #undef s_tau
 }
 
@@ -981,13 +859,6 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ h
     MERGE_STAMP(2);
 }
 
-// dynamic LDS the tail of band_topk_kernel<..., TAIL> needs (see its carve-up), for a workgroup of `waves` waves
-size_t band_tail_lds_bytes(int nbands, int k, int L, int waves)
-{
-    const size_t n_all = (size_t)nbands * k, Kp = (size_t)((k + 3) & ~3);
-    return (((4 * n_all + 2 + 2 + L + 1 + 3) & ~(size_t)3) + (size_t)waves * 8 * Kp) * 4;
-}
-
 struct Plan {
     int vec, rows, nbands, panel_strips, nwaves, cap, t_sub;   // rows / nbands: equal bands (og_hmp_nms_f32)
     BandMap bm;       // the band kernel's work items
@@ -1004,7 +875,7 @@ int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
-int device_cu_count();
+inline int device_cu_count() { return og_cu_count(); }
 
 bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
 {
@@ -1056,15 +927,10 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     return true;
 }
 
-struct Pairing {   // og_generate_limbs_f32: the limbs are paired by the band launch itself, or by the merge launch
+struct Pairing {   // og_generate_limbs_f32: the merge launch pairs the limbs as well
     og_collect::Args a;
     int nd, N;
-    int *tickets;          // zero-filled ticket area for the in-launch tail (or nullptr) and its size
-    size_t ticket_bytes;
-    int tail_in_band;
 };
-inline int pair_N(const Pairing *p) { return p ? p->N : 0; }
-inline int pair_L(const Pairing *p) { return p ? p->a.L : 0; }
 
 template <bool NMS_MODE, bool FUSED = false>
 int run_topk(const float *in, long planes, int H, int W, int k, float *out_scores, int64_t *out_inds,
@@ -1099,39 +965,18 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
     const dim3 block(64 * (p.nwaves + (helper & 1)));
     const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
-    const TailArgs no_tail{};
-    if constexpr (NMS_MODE && !FUSED) {
-        // og_generate_limbs_f32 with OG_LIMBS_TAIL_IN_BAND: merge + pairing inside the band launch, by last arrivers
-        const int tail_in_band = pair ? pair->tail_in_band : 0;
-        const int waves = p.nwaves + (helper & 1);
-        const size_t tlds = pair ? band_tail_lds_bytes(p.max_bands, k, pair->a.L, waves) : 0;
-        const size_t n_tickets = (size_t)planes + (size_t)pair_N(pair) * pair_L(pair) + 1;
-        if (pair && pair->tickets && tail_in_band && p.vec == 4 && tlds <= 64 * 1024 && n_tickets * sizeof(int) <= pair->ticket_bytes &&
-            (size_t)planes * k < (1u << 27)) {
-            TailArgs tl;
-            tl.tickets = pair->tickets;
-            tl.out_scores = out_scores; tl.out_inds = out_inds;
-            tl.ca = pair->a; tl.nd = pair->nd; tl.planes = (int)planes;
-            tl.t_sub = min(k, max(2, (k + p.bm.b_lo - 1) / p.bm.b_lo + 1));   // one list per band in this form
-            hipLaunchKernelGGL((band_topk_kernel<4, true, kPrefetch, kBandAbl, false, true>), dim3(padded), block, lds > tlds ? lds : tlds,
-                               stream, in, keys, hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips,
-                               (int)total, padded, helper, 1, tl);
-            OG_LAUNCH_CHECK(name);
-            return 1;   // paired
-        }
-    }
     if (FUSED)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded,
-                           helper, wl, no_tail);
+                           helper, wl);
     else if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
-                           wl, no_tail);
+                           wl);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
-                           wl, no_tail);
+                           wl);
     OG_LAUNCH_CHECK(name);
     // dynamic LDS the merge kernels may ask for without raising the 64 KiB default: their static __shared__ words (bounds,
     // counters: 24 B) come on top
@@ -1154,8 +999,6 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
-
-#include "k1_single.inc"
 
 }  // namespace
 
@@ -1215,10 +1058,9 @@ OG_API int og_hmp_nms_f32(const float *heat, long planes, int H, int W, float *o
 // ---- a8+a9+a10 in one launch: LimbsCollect.generate_limbs  decoder/collect.py:62-236 ----
 namespace {
 
-#ifndef OG_K1_SINGLE_PF
-#define OG_K1_SINGLE_PF 3
-#endif
-constexpr int kSinglePF = OG_K1_SINGLE_PF;   // rows in flight per streaming wave
+// head of every og_generate_limbs_f32 workspace: reserved (the one-launch forms of rounds 2 / 3 kept their tickets there;
+// tools/experiments/k1_single.inc); the size stays so that workspaces sized by earlier builds keep working
+constexpr size_t kP2TicketBytes = 64 * 1024;
 
 size_t two_step_bytes(int N, int C, int H, int W, int k, bool need_lists)
 {
@@ -1232,19 +1074,16 @@ size_t two_step_bytes(int N, int C, int H, int W, int k, bool need_lists)
 OG_API size_t og_generate_limbs_workspace_bytes(int N, int C, int H, int W, int k)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return 0;
-    P2Plan p;
-    const size_t single = make_plan2((long)N * C, H, W, k, C, device_cu_count(), &p) ? p.bytes : 0;
-    const size_t two = two_step_bytes(N, C, H, W, k, true);
-    return single > two ? single : two;
+    return two_step_bytes(N, C, H, W, k, true);
 }
 
-OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
-                                 const float *scales, int scales_mode, const float *jitter, int jitter_mode,
-                                 int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
-                                 float thre_hmp, float min_len, float resize_factor, float *topk_scores,
-                                 int64_t *topk_inds, float *limbs, int flags, void *workspace, size_t workspace_bytes, void *stream)
+static int generate_limbs_impl(const char *name, const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
+                               const float *scales, int scales_mode, const float *jitter, int jitter_mode,
+                               int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                               float thre_hmp, float min_len, float resize_factor, float *topk_scores,
+                               int64_t *topk_inds, float *limbs, const int32_t *limb_perm, const int32_t *reserve_mask,
+                               void *workspace, size_t workspace_bytes, void *stream)
 {
-    const char *name = "og_generate_limbs_f32";
     OG_REQUIRE(hmps_hr && offs && jf && jt && limbs && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE((topk_scores == nullptr) == (topk_inds == nullptr), OG_EINVAL, "%s: topk_scores and topk_inds go together", name);
     OG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && L > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
@@ -1260,56 +1099,54 @@ OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int of
     OG_REQUIRE((long)H * W >= k, OG_EINVAL, "%s: selected index k out of range (k=%d > H*W=%ld)", name, k, (long)H * W);
     OG_REQUIRE(2l * (H + W) - 4 >= k, OG_EINVAL, "%s: plane border smaller than k", name);
     OG_REQUIRE((uintptr_t)workspace % 16 == 0, OG_EINVAL, "%s: workspace must be 16-byte aligned", name);
-    const og_collect::Args ca{offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode,
-                              jitter, jitter_mode, limbs};
-    P2Plan p;
-    const bool single = (flags & OG_LIMBS_SINGLE_LAUNCH) != 0 && (uintptr_t)hmps_hr % 16 == 0 &&
-                        make_plan2((long)N * C, H, W, k, C, device_cu_count(), &p);
-    if (!single) {  // the default, and shapes the persistent kernel does not take: band top-k, then merge + pairing
-        const bool own_lists = topk_scores == nullptr;
-        const size_t need = two_step_bytes(N, C, H, W, k, own_lists);
-        OG_REQUIRE(need != 0, OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d", name, W, k);
-        OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, need);
-        // the ticket area at the head of the workspace belongs to the persistent kernel: stay clear of it
-        char *ws2 = (char *)workspace + kP2TicketBytes;
-        const size_t topk = og_align_up(og_topk_workspace_bytes((long)N * C, H, W, k), 256);
-        float *sc = own_lists ? reinterpret_cast<float *>(ws2 + topk + (size_t)N * C * k * 8) : topk_scores;
-        int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
-        // two launches: the merge launch pairs the limbs as well (OG_K1_PAIR_IN_MERGE=0: merge, then the collect kernel)
-        static const int pair_in_merge = env_int("OG_K1_PAIR_IN_MERGE", 1);
-        // the ticket area at the head of the workspace (all zero between calls) serves the in-launch tail as well
-        const Pairing pr{ca, vector_nd, N, reinterpret_cast<int *>(workspace), (size_t)kP2TicketBytes - 4096,
-                         (flags & OG_LIMBS_TAIL_IN_BAND) != 0};
-        const bool can_pair = (pair_in_merge || pr.tail_in_band) && (long)H * W < (1l << 31) && k <= 2048;
-        const int rc = run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
-                                      can_pair ? &pr : nullptr);
-        if (rc < 0 || rc == 1) return rc < 0 ? rc : OG_OK;
-        return og_collect_limbs_full_f32(sc, id, offs, off_is_lowres, vector_nd, scales, scales_mode, jitter, jitter_mode, N, C,
-                                         H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs, stream);
-    }
-    OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
-    P2Args a;
-    a.in = hmps_hr;
-    a.planes = N * C; a.H = H; a.W = W; a.k = k; a.kpad = p.kpad; a.cap = p.cap;
-    a.balance = p.balance; a.bal_magic = p.magic;
-    a.bal = reinterpret_cast<int *>((char *)workspace + p.bal_off);
-    a.teams = p.teams; a.panels = p.panels; a.panel_strips = p.panel_strips;
-    a.maxseg = p.maxseg; a.total_rows = p.total_rows;
-    a.tickets = reinterpret_cast<int *>((char *)workspace + p.tick_off);
-    a.wg_cnt = reinterpret_cast<int *>((char *)workspace + p.cnt_off);
-    a.wg_keys = reinterpret_cast<uint64_t *>((char *)workspace + p.keys_off);
-    a.group = C;
-    a.out_scores = topk_scores; a.out_inds = topk_inds;
-    a.collect = 1; a.nd = vector_nd;
-    a.ca = ca;
-    auto kern = generate_limbs_kernel<kSinglePF>;
-    if (p.lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: %s", name, hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(kern, dim3(p.G), dim3(64 * (p.teams * p.panels + 1)), p.lds, (hipStream_t)stream, a);
-    OG_LAUNCH_CHECK(name);
-    return OG_OK;
+    og_collect::Args ca{offs, off_is_lowres, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, scales, scales_mode,
+                        jitter, jitter_mode, limbs};
+    if (limb_perm) { ca.limb_perm = limb_perm; ca.reserve = reserve_mask; ca.flip_N = N; }
+    // band top-k, then ONE launch that merges the band lists and pairs the limbs
+    const bool own_lists = topk_scores == nullptr;
+    const size_t need = two_step_bytes(N, C, H, W, k, own_lists);
+    OG_REQUIRE(need != 0, OG_EUNSUPPORTED, "%s: unsupported W=%d or k=%d", name, W, k);
+    OG_REQUIRE(workspace_bytes >= need, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, need);
+    char *ws2 = (char *)workspace + kP2TicketBytes;
+    const size_t topk = og_align_up(og_topk_workspace_bytes((long)N * C, H, W, k), 256);
+    float *sc = own_lists ? reinterpret_cast<float *>(ws2 + topk + (size_t)N * C * k * 8) : topk_scores;
+    int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
+    const Pairing pr{ca, vector_nd, N};
+    const bool can_pair = (long)H * W < (1l << 31) && k <= 2048;
+    const int rc = run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
+                                  can_pair ? &pr : nullptr);
+    if (rc < 0 || rc == 1) return rc < 0 ? rc : OG_OK;
+    // (shapes whose merge + pairing stage does not fit the LDS: the lists are complete, pair them with the collect kernel)
+    OG_REQUIRE(!limb_perm, OG_EUNSUPPORTED, "%s: k = %d is too large for the merge-and-pair stage of the flip-folded form", name, k);
+    return og_collect_limbs_full_f32(sc, id, offs, off_is_lowres, vector_nd, scales, scales_mode, jitter, jitter_mode, N, C,
+                                     H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, limbs, stream);
+}
+
+OG_API int og_generate_limbs_f32(const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
+                                 const float *scales, int scales_mode, const float *jitter, int jitter_mode,
+                                 int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
+                                 float thre_hmp, float min_len, float resize_factor, float *topk_scores,
+                                 int64_t *topk_inds, float *limbs, int flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    (void)flags;    // reserved (the one-launch forms of rounds 2 / 3 were selected here): pass 0
+    return generate_limbs_impl("og_generate_limbs_f32", hmps_hr, offs, off_is_lowres, vector_nd, scales, scales_mode, jitter,
+                               jitter_mode, N, C, H, W, jf, jt, L, k, thre_hmp, min_len, resize_factor, topk_scores, topk_inds,
+                               limbs, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// generate_limbs with flip_augment's OFFSET merge (decoder/factory.py:129-138) folded into the offset sampling: offs_pair is the
+// stride-4 offset head output for [images | mirrored images], (2N, 2L, H/4, W/4)
+OG_API int og_generate_limbs_flip_f32(const float *hmps_hr, const float *offs_pair, const int32_t *limb_perm,
+                                      const int32_t *reserve_mask, int N, int C, int H, int W, const int32_t *jf,
+                                      const int32_t *jt, int L, int k, float thre_hmp, float min_len, float resize_factor,
+                                      float *topk_scores, int64_t *topk_inds, float *limbs, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_generate_limbs_flip_f32";
+    OG_REQUIRE(limb_perm && reserve_mask, OG_EINVAL, "%s: null pointer", name);
+    return generate_limbs_impl(name, hmps_hr, offs_pair, 1, 2, nullptr, 0, nullptr, 0, N, C, H, W, jf, jt, L, k, thre_hmp, min_len,
+                               resize_factor, topk_scores, topk_inds, limbs, limb_perm, reserve_mask, workspace, workspace_bytes,
+                               stream);
 }
 
 #ifdef OG_K1_STAMPS

@@ -41,7 +41,7 @@ struct Row4 {
 
 __global__ void __launch_bounds__(64 * kCubicMaxWaves)
 bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, int w, int rows, int nbands,
-                int panel_cols, int total, int padded, int store_policy)
+                int panel_cols, int total, int padded, int store_policy, const int32_t *__restrict__ kp_perm, int flip_planes, int C)
 {
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
@@ -53,6 +53,13 @@ bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, i
     const bool interior = lane >= 2 && lane < 2 + q_cnt;
     const int qc = min(max(q, 0), w - 1);              // index clamp == torch's tap clamp
     const float *s = src + (size_t)plane * h * w;
+    // flip-test folded into the loads (PostProcess.flip_augment, decoder/factory.py:101-106): src holds [images | mirrored
+    // images]; every source pixel is (a + b[kp_perm[ch]][y][w-1-x]) / 2 -- the value og_flip_merge_f32 would have written
+    const float *s2 = nullptr;
+    if (kp_perm) {
+        const int n = plane / C, ch = plane - n * C;
+        s2 = src + ((size_t)flip_planes + (size_t)n * C + kp_perm[ch]) * h * w;
+    }
     float *d = dst + (size_t)plane * (4 * h) * (4 * w);
     const int p0 = band * rows, p1 = min(p0 + rows, h);
     const __amdgpu_buffer_rsrc_t plane_rsrc = __builtin_amdgcn_make_buffer_rsrc(d, 0, (int)((size_t)16 * h * w * sizeof(float)), 0x00020000);
@@ -65,7 +72,8 @@ bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, i
 
     auto xpass = [&](int row) {
         const int rc = min(max(row, 0), h - 1);
-        const float c0 = s[(size_t)rc * w + qc];
+        float c0 = s[(size_t)rc * w + qc];
+        if (s2) c0 = (c0 + s2[(size_t)rc * w + (w - 1 - qc)]) / 2.f;
         const float cm1 = og_from_lane_below(c0), cm2 = og_from_lane_below(cm1);
         const float cp1 = og_from_lane_above(c0), cp2 = og_from_lane_above(cp1);
         Row4 o;
@@ -147,9 +155,9 @@ bilinear4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, 
 
 }  // namespace
 
-OG_API int og_upsample_bicubic4_f32(const float *src, long planes, int h, int w, float *dst, void *stream)
+static int bicubic4_launch(const char *name, const float *src, long planes, int h, int w, float *dst, const int32_t *kp_perm, int C,
+                           void *stream)
 {
-    const char *name = "og_upsample_bicubic4_f32";
     OG_REQUIRE(src && dst, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(planes > 0 && h > 0 && w > 0, OG_EINVAL, "%s: bad shape", name);
     OG_REQUIRE((uintptr_t)dst % 16 == 0, OG_EINVAL, "%s: dst must be 16-byte aligned", name);
@@ -163,9 +171,23 @@ OG_API int og_upsample_bicubic4_f32(const float *src, long planes, int h, int w,
     const int padded = (int)((total + 7) / 8 * 8);
     static const int store_policy = getenv("OG_K1A_STORE") ? atoi(getenv("OG_K1A_STORE")) : 0;
     hipLaunchKernelGGL(bicubic4_kernel, dim3(padded), dim3(64 * nwaves), 0, (hipStream_t)stream, src, dst, h, w, rows,
-                       nbands, panel_cols, (int)total, padded, store_policy);
+                       nbands, panel_cols, (int)total, padded, store_policy, kp_perm, (int)planes, C);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
+}
+
+OG_API int og_upsample_bicubic4_f32(const float *src, long planes, int h, int w, float *dst, void *stream)
+{
+    return bicubic4_launch("og_upsample_bicubic4_f32", src, planes, h, w, dst, nullptr, 1, stream);
+}
+
+// flip_augment's heatmap merge (decoder/factory.py:101-106) + F.interpolate(x4, bicubic) (:74-75) in one pass
+OG_API int og_upsample_bicubic4_flip_f32(const float *hm_pair, const int32_t *kp_perm, int N, int C, int h, int w, float *dst, void *stream)
+{
+    const char *name = "og_upsample_bicubic4_flip_f32";
+    OG_REQUIRE(kp_perm, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(N > 0 && C > 0, OG_EINVAL, "%s: bad shape", name);
+    return bicubic4_launch(name, hm_pair, (long)N * C, h, w, dst, kp_perm, C, stream);
 }
 
 OG_API int og_upsample_bilinear4_f32(const float *src, long planes, int h, int w, float *dst, void *stream)

@@ -21,8 +21,7 @@ class LimbsCollect(object):
     K2 samples the stride-4 maps at the peaks with the arithmetic of F.interpolate(x4).
 
     On hi-res heatmaps the whole of generate_limbs -- NMS, top-k and the pairing -- is ONE C call
-    (og_generate_limbs_f32): two launches queued back to back (band top-k; merge + pairing), or with `single_launch = True` (OG_K1_SINGLE=1) one
-    persistent kernel with identical results (measured slower on MI355X).
+    (og_generate_limbs_f32): two launches queued back to back (band top-k; merge + pairing).
     """
 
     def __init__(self, hmp_s, off_s, *, topk=40, thre_hmp=0.08, min_len=3,
@@ -40,7 +39,6 @@ class LimbsCollect(object):
         self.include_scale = include_scale
         self.use_jitter_offset = use_jitter_offset
         self.jtypes_f, self.jtypes_t = self.pack_jtypes(skeleton)
-        self.single_launch = os.environ.get('OG_K1_SINGLE', '0') == '1'
         LOG.info('%d limbs, keypoint threshold %.4f, offset/heatmap unit ratio %.3f',
                  len(skeleton), thre_hmp, self.resize_factor)
 
@@ -71,6 +69,26 @@ class LimbsCollect(object):
             'spatial resolution should be equal'
         return self._collect(hmps_hr, offs_lr, off_is_lowres=True, vector_nd=vector_nd, scales=scmps_lr,
                              scales_mode=2 if scale_inter == 'bicubic' else 3, jitter=self._jitter(jomps_lr), jitter_mode=3)
+
+    def generate_limbs_flip(self, hmps_hr, offs_pair_lr, limb_perm, reserve_mask):
+        """generate_limbs_lowres on the flip-merged offsets WITHOUT merging them first: offs_pair_lr = the stride-4 offset head
+        output for [images | mirrored images], (2N, 2L, h, w); every sampled tap is computed as PostProcess.flip_augment would
+        have written it (decoder/factory.py:129-138).  2-component offsets, no scale / jitter head."""
+        hmps_hr = _lib.require_device(hmps_hr, 'hmps_hr')
+        offs = _lib.require_device(offs_pair_lr, 'offs')
+        n, c, h, w = hmps_hr.shape
+        n_limbs = len(self.skeleton)
+        assert tuple(offs.shape) == (2 * n, 2 * n_limbs, h // 4, w // 4), 'offsets of [images | mirrored images] at stride 4'
+        dev, lib = hmps_hr.device, _lib.load()
+        limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
+        jf, jt = _lib.int_table(self.jtypes_f, dev), _lib.int_table(self.jtypes_t, dev)
+        with _lib.stage_timer('k1_generate_limbs', dev):
+            ws = _lib.workspace(dev, lib.og_generate_limbs_workspace_bytes(n, c, h, w, self.K), 'limbs')   # zero-filled
+            _lib.check(lib.og_generate_limbs_flip_f32(
+                _lib.ptr(hmps_hr), _lib.ptr(offs), _lib.ptr(_lib.int_table(limb_perm, dev)), _lib.ptr(_lib.int_table(reserve_mask, dev)),
+                n, c, h, w, _lib.ptr(jf), _lib.ptr(jt), n_limbs, self.K, float(self.thre_hmp), float(self.min_len),
+                float(self.resize_factor), None, None, _lib.ptr(limbs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+        return limbs
 
     def generate_limbs_fused(self, hmps_lr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic', jomps_lr=None):
         """Same limbs as generate_limbs(F.interpolate(hmps_lr, x4, 'bicubic'), [], F.interpolate(offs_lr, x4,
@@ -119,7 +137,7 @@ class LimbsCollect(object):
                     _lib.ptr(scales) if scales is not None else None, int(scales_mode),
                     _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w, _lib.ptr(jf), _lib.ptr(jt),
                     n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor), None, None,
-                    _lib.ptr(limbs), _lib.OG_LIMBS_SINGLE_LAUNCH if self.single_launch else 0, _lib.ptr(ws), ws.numel(),
+                    _lib.ptr(limbs), 0, _lib.ptr(ws), ws.numel(),
                     _lib.stream_ptr(dev)), lib)
                 return limbs
             scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)   # K1-fused: upsample inside

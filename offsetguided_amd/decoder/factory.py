@@ -25,6 +25,19 @@ from .offset import pack_jtypes, scored_offset
 LOG = logging.getLogger(__name__)
 
 
+def upsample4_flip(hm_pair, kp_perm):
+    """F.interpolate((hm[:N] + flip(hm[N:])[:, kp_perm]) / 2, scale_factor=4, mode='bicubic') in ONE pass over the stride-4 maps of
+    [images | mirrored images]: flip_augment's heatmap merge (decoder/factory.py:101-106) rides on the loads of the upsampling."""
+    x = _lib.require_device(hm_pair, 'feature map')
+    lib = _lib.load()
+    n2, c, h, w = x.shape
+    out = torch.empty((n2 // 2, c, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
+    with _lib.stage_timer('k1a_upsample', x.device):
+        _lib.check(lib.og_upsample_bicubic4_flip_f32(_lib.ptr(x), _lib.ptr(_lib.int_table(kp_perm, x.device)), n2 // 2, c, h, w,
+                                                     _lib.ptr(out), _lib.stream_ptr(x.device)), lib)
+    return out
+
+
 def upsample4(x, mode):
     """F.interpolate(x, scale_factor=4, mode=mode) with torch-CPU fp32 rounding, as a HIP kernel."""
     x = _lib.require_device(x, 'feature map')
@@ -44,6 +57,7 @@ class _HostSlot:
         self.poses = torch.empty(poses_shape, dtype=torch.float32).pin_memory()
         self.meta = torch.empty(meta_shape, dtype=torch.int32).pin_memory()
         self.busy = False
+        self.orphan = None    # event of a handle that was dropped unread while its copy was still in flight
 
 
 class PendingPoses:
@@ -78,12 +92,19 @@ class PendingPoses:
             self._slot = None
         self._limbs = self._poses = self._meta = None   # device tensors are no longer needed
 
-    def __del__(self):   # a handle dropped unread: wait for the copy that targets its slot, then free it
-        if getattr(self, '_slot', None) is not None:
+    def __del__(self):
+        # A handle dropped unread: a finalizer never waits on the GPU (it would stall whichever thread runs the garbage
+        # collector, and raise at interpreter shutdown).  If the copy that targets the slot has finished the slot is free again;
+        # otherwise the slot keeps the event and submit() takes it back once the event has completed.
+        slot = getattr(self, '_slot', None)
+        if slot is not None:
             try:
-                self._event.synchronize()
-            finally:
-                self._slot.busy = False
+                if self._event.query():
+                    slot.busy = False
+                else:
+                    slot.orphan = self._event
+            except Exception:  # noqa: BLE001  torch already torn down
+                pass
 
 
 class PostProcess(torch.nn.Module):
@@ -114,7 +135,10 @@ class PostProcess(torch.nn.Module):
         # False (default): K1a materialises the hi-res heatmaps and K1 streams them, the reference's
         # structure and the HBM-roofline path.  True: K1-fused upsamples inside the NMS kernel
         # (identical results, 16x less HBM traffic).
-        self.fused_upsample = False
+        self.fused_upsample = os.environ.get('OG_FUSED_UPSAMPLE', '0') == '1'
+        # flip-test (2-component offsets, no scale / jitter head): flip_augment's merge rides on the loads of K1a and on the
+        # offset sampling of K1 instead of running as its own pass (K0, og_flip_merge_f32); identical results
+        self.fold_flip = os.environ.get('OG_FOLD_FLIP', '1') != '0'
         # submit(): grouping (one workgroup per image, latency-bound) and the pose D2H copy run on their own stream, so
         # the caller's next launches (the following batch's backbone) do not queue behind them
         self.group_on_side_stream = os.environ.get('OG_GROUP_SIDE_STREAM', '1') != '0'
@@ -146,6 +170,9 @@ class PostProcess(torch.nn.Module):
             # a pinned slot nobody is waiting on (the pool grows with the number of outstanding handles: a third submit()
             # before the first result() gets a third slot instead of overwriting the first batch's landing area)
             pool = self._pinned.setdefault((tuple(poses.shape), tuple(meta.shape)), [])
+            for sl in pool:     # slots of handles that were dropped unread: free once their copy has landed
+                if sl.orphan is not None and sl.orphan.query():
+                    sl.busy, sl.orphan = False, None
             slot = next((sl for sl in pool if not sl.busy), None)
             if slot is None:
                 slot = _HostSlot(poses.shape, meta.shape)
@@ -199,6 +226,13 @@ class PostProcess(torch.nn.Module):
         offs = out_offsets[self.feat_stage]
         scmps = out_scales[self.feat_stage]
         vector_nd = 2
+        if (flip_test and self.fold_flip and not cat_flip_offs and not scored_off and not self.fused_upsample
+                and self.inter_mode == 'bicubic' and not (self.include_scale and isinstance(scmps, torch.Tensor))
+                and not (self.include_jitter_offset and isinstance(jomps, torch.Tensor))):
+            n_limbs = offs.shape[1] // 2
+            keep = [1 if l in self.limbs_flips[1] else 0 for l in range(n_limbs)]
+            hmps_hr = upsample4_flip(hmps, self.keypoints_flips)
+            return self.limb_collect.generate_limbs_flip(hmps_hr, offs, self.limbs_flips[0], keep)
         if flip_test:
             hmps, jomps, offs, scmps, vector_nd = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, vector_nd)
         if scored_off:

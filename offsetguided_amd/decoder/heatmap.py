@@ -16,10 +16,17 @@ def _planes(t):
 
 
 def hmp_NMS(heat, kernel=3):
-    """Keep 3x3 local maxima (zero padding), zero the rest: heat * (maxpool(heat) == heat)."""
-    if kernel != 3:
-        raise NotImplementedError("hmp_NMS: only the 3x3 window used by the decoder is implemented")
+    """Keep kernel x kernel local maxima (zero padding), zero the rest: heat * (maxpool(heat) == heat).
+
+    kernel = 3 (the decoder's window, decoder/heatmap.py:15) is the hand-written HIP kernel; any other odd window runs the
+    reference's own three device ops (pad, max_pool2d, multiply: exact comparisons, so the result is the reference's bit for
+    bit); an even window fails as it does there (the padded pool no longer returns the input's size)."""
     heat = _lib.require_device(heat, "hmp_NMS(heat)")
+    if kernel != 3:
+        import torch.nn.functional as F
+        pad = (kernel - 1) // 2
+        hmax = F.max_pool2d(F.pad(heat, [pad] * 4), (kernel, kernel), stride=1, padding=0)
+        return heat * (hmax == heat).float()
     lib = _lib.load()
     planes, h, w = _planes(heat)
     out = torch.empty_like(heat)

@@ -2,14 +2,14 @@
 
 What this file adds to the eager module is the shape the hardware wants:
   * every BatchNorm folded into the preceding convolution (160 BN layers disappear);
-  * bf16 (or fp16, the reference's apex-O2 arithmetic) activations / weights in channels-last (NHWC) layout;
-  * the 3x3 stride-1 convolutions -- 92 % of the FLOPs -- on the hand-written MFMA kernels of csrc/conv3x3.hip
-    (og_conv3x3_bf16: halo-tiled direct convolution for the 160x160 / 80x80 / 40x40 levels, split-K implicit GEMM with
-    the reduction inside the launch for 20x20 / 10x10 / 5x5), bias + ReLU + residual add fused into their epilogues,
-    fp32 accumulation in the MFMA accumulators; the stride-2 / projection layers of the small levels on the same
-    split-K kernel (og_conv2d_bf16, og_conv2d_proj_bf16), the stem on csrc/stem.hip;
-  * what is left on MIOpen (large stride-2 3x3, 1x1 junctions: 0.7 ms of 7) gets its bias / ReLU / residual pass and the
-    nearest-x2-upsample + add of every hourglass merge as ONE hand-written HIP pass each (csrc/epilogue.hip);
+  * fp16 (default: the reference's apex-O2 arithmetic) or bf16 activations / weights in channels-last (NHWC) layout;
+  * EVERY convolution on a hand-written MFMA kernel, bias + ReLU + residual add fused into its epilogue, fp32 accumulation:
+    og_conv3x3_tiled_* / og_conv3x3s2_tiled_* / og_conv1x1_tiled_* for the 160x160 ... 20x20 levels (two 4-wave workgroups
+    per CU, pre-tiled weights), the split-K kernel og_conv2d_* / og_conv2d_proj_* for 10x10 / 5x5 and the stride-2 / projection
+    layers there (optionally the band-resident og_conv_band_*), og_stem7x7_* for the stem, og_conv1x1_heads_* for the heads;
+    a shape none of them serves falls back to torch's convolution + one og_bias_act_* pass;
+  * the hourglass merges (nearest x2 upsample + add) on the epilogue of the convolution below them where that kernel is the
+    tiled one, else one og_upsample2_add_* pass;
   * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only), all of them as one
     1x1 convolution whose result leaves as dense fp32 NCHW tensors, the layout the HIP decoder kernels stream;
   * the whole forward (~170 launches, the up1 branches of every level forked onto side streams) is captured once into
@@ -19,6 +19,13 @@ The result keeps the reference nesting [ (hmps[S], bg[S], jo[S]), (offs[S], spre
 
 Building an engine does not touch the caller's module: the weights are folded from its state_dict, the module's
 train / eval flag and device stay as they are.
+
+Environment switches (read at import; the measured-best value is the default): OG_CONV_TILED (7: bit 0 / 1 / 2 = 3x3 stride 1 /
+3x3 stride 2 / 1x1 layers on the tiled kernels), OG_CONV_UP2 (1: merges on the producing convolution's epilogue),
+OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (1: capture order at the forks of
+depth >= 1), OG_CONV_BAND_MAX_PIXELS (0) / OG_CONV_BAND_CHAIN (0): the band-resident kernel, OG_ENGINE_WHATIF (timing diagnosis,
+wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
+EXPERIMENTS.md and no longer exist as switches.
 """
 import os
 import threading
@@ -64,21 +71,15 @@ def _epilogue(y, bias32, bias_lp, skip, relu, fused):
     return F.relu_(y) if relu else y
 
 
-# Layers with at most this many output pixels (N*H*W) run on the hand-written split-K MFMA kernel
-# (og_conv3x3_bf16, epilogue fused) instead of MIOpen + og_bias_act_bf16: the 20x20 / 10x10 / 5x5 levels at bs8.
-CONV3X3_MAX_PIXELS = int(os.environ.get('OG_CONV3X3_MAX_PIXELS', '4096'))
-# ... and layers with at least this many pixels run on its halo-tiled variant where a tile shape exists: H, W multiples
-# of 16 (the 160x160 / 80x80 levels) or W == 40 (the 40x40 level).
-CONV3X3_HALO_MIN_PIXELS = int(os.environ.get('OG_CONV3X3_HALO_MIN_PIXELS', '8192'))
-# The large levels' 3x3 layers run on the second-generation tiled kernel (og_conv3x3_tiled_*: two workgroups per CU,
-# pre-tiled weights) where it serves the shape; OG_CONV_TILED=0 keeps them on the first-generation halo kernel.
-CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))   # bit 0: 3x3 stride 1, bit 1: 3x3 stride 2 (og_conv3x3s2_tiled_*), bit 2: 1x1
-# bit 2 (4): pointwise layers of the large levels (junction, projection skips, heads) on og_conv1x1_tiled_* / og_conv1x1_heads_*
-CONV_PW_MIN_PIXELS = int(os.environ.get('OG_CONV_PW_MIN_PIXELS', '8192'))
-# 3x3 stride-1 layers with at least this many output pixels go to the tiled kernel where it serves the shape (20x20 at batch 8
-# = 3 200 pixels: 20 x 4 tiles split 3 ways along K)
-CONV_TILED_MIN_PIXELS = int(os.environ.get('OG_CONV_TILED_MIN_PIXELS', '2048'))
-CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # stride-2 3x3 layers on the split-K kernel up to here
+# Layers with at most this many output pixels (N*H*W) run on the split-K MFMA kernel (og_conv2d_*, epilogue fused): the 10x10 /
+# 5x5 levels at batch 8, and the stride-2 layers whose output is that small.
+CONV3X3_MAX_PIXELS = 4096
+CONV_S2_MAX_PIXELS = 4096
+# The large levels' layers run on the tiled kernels (og_conv3x3_tiled_* / og_conv3x3s2_tiled_* / og_conv1x1_tiled_*: two workgroups
+# per CU, pre-tiled weights) where they serve the shape: bit 0 = 3x3 stride 1, bit 1 = 3x3 stride 2, bit 2 = 1x1 / heads.
+CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))
+CONV_PW_MIN_PIXELS = 8192        # 1x1 layers below this stay on torch's convolution (the deep projections ride on conv2 instead)
+CONV_TILED_MIN_PIXELS = 2048     # 20x20 at batch 8 = 3 200 pixels: 20 x 4 tiles split along K
 # OG_CONV_BAND_MAX_PIXELS = P (default 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with at
 # most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: K split over the waves of a
 # workgroup, no slabs / tickets) where it serves the shape -- 1024 = the 10x10 / 5x5 levels at batch 8 -- and with
@@ -89,21 +90,11 @@ CONV_S2_MAX_PIXELS = int(os.environ.get('OG_CONV_S2_MAX_PIXELS', '4096'))   # st
 # their tests and tools stay (the split-K kernel keeps these layers).
 CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '0'))
 CONV_BAND_CHAIN = int(os.environ.get('OG_CONV_BAND_CHAIN', '0'))
-_chain_ws = {}
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
 BRANCHES = int(os.environ.get('OG_ENGINE_BRANCHES', '1'))
 BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fork up1 only at levels <= this depth
-# OG_ENGINE_BRANCH_DELAY = D: the up1 branches of the levels above depth D are not started at their fork point but when the
-# trunk ENTERS depth D (they only need the level's input): the trunk then descends through the large levels with the chip
-# to itself, and the bulk of the up1 branches runs beside the latency-bound 20x20 / 10x10 / 5x5 chain instead of before it.
-BRANCH_DELAY = int(os.environ.get('OG_ENGINE_BRANCH_DELAY', '0'))
-# OG_ENGINE_SIDE_SHARED = D: the up1 branches of the levels above depth D share ONE side stream (they run one after the other,
-# each with the chip's bulk share to itself, beside the trunk) instead of a stream each; with OG_ENGINE_BRANCH_DELAY they are
-# submitted deepest level first, the order in which the trunk joins them on its way up.
-SIDE_SHARED = int(os.environ.get('OG_ENGINE_SIDE_SHARED', '0'))
-_shared_side = {}
 # OG_ENGINE_TRUNK_FIRST = D (0 = off): at the levels of depth >= D the up1 branch is queued on its side stream AFTER the first kernel
 # of the trunk below the fork point (it still depends on the fork point only, through an event recorded there).  The HIP graph
 # executor keeps a node on the queue of the parent whose FIRST child it is (capture order): with the branch captured first,
@@ -112,8 +103,7 @@ _shared_side = {}
 # and merges, a fork costs it ~6 us instead (the release behind the fork point).
 TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
 CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
-BRANCH_MIN_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MIN_DEPTH', '0'))   # levels above this depth run up1 in the trunk, unforked
-_pending_branches = []
+_chain_ws = {}
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
 class _Issuer(threading.local):
@@ -151,7 +141,7 @@ class _Conv:
         self.w_tiled = None          # weights in og_conv3x3_tiled_*'s layout, made on first use
         self.w_band = None           # weights (+ projection) in og_conv_band_*'s fragment order, made on first use
         self.fused = fused and w.shape[0] % 8 == 0
-        strides = ((1, 1), (2, 2)) if int(os.environ.get('OG_ENGINE_CONV_S2', '1')) else ((1, 1),)
+        strides = ((1, 1), (2, 2))
         self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) in strides
                        and tuple(conv.padding) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
 
@@ -164,7 +154,7 @@ class _Conv:
     def _whatif_skipped(self, x):
         """OG_ENGINE_WHATIF=<classes> (diagnostic, WRONG RESULTS): layers of the named classes produce an uninitialised
         output instead of running -- the forward time that disappears is that class's share of the critical path.
-        Classes: s2big (MIOpen stride-2 3x3), 1x1 (MIOpen 1x1), chain (split-K small levels), c160 / c80 / c40 (halo)."""
+        Classes: s2big (large stride-2 3x3), 1x1 (pointwise), chain (the small levels), c160 / c80 / c40 (tiled 3x3 by level)."""
         if not _WHATIF:
             return None
         n, c, h, w = x.shape
@@ -187,14 +177,12 @@ class _Conv:
             pixels = n * ((h - 1) // st + 1) * ((w - 1) // st + 1)
             if self.band_ok(x):
                 return self.band(x, skip)
-            # stride 2: the split-K kernel wins where M is small (40x40 -> 20x20 and below at bs8: 30 / 15 / 12 us against
-            # MIOpen + epilogue 48 / 30 / 26); the large stride-2 layers stay on MIOpen (CK is 1.2-1.6x faster there)
+            # 3x3 stride 1 on the tiled kernel where it serves the shape, the small levels (and the small stride-2 layers) on the
+            # split-K kernel
             if (st == 1 and (CONV_TILED & 1) and pixels >= CONV_TILED_MIN_PIXELS and self.w.shape[0] % 128 == 0
                     and _lib.load().og_conv3x3_tiled_supported(n, h, w, c, self.w.shape[0])):
                 return self._hip(x, skip)
-            if pixels <= (CONV_S2_MAX_PIXELS if st == 2 else CONV3X3_MAX_PIXELS) or (st == 1 and (
-                    pixels >= CONV3X3_HALO_MIN_PIXELS and self.w.shape[0] % 128 == 0
-                    and ((h % 16 == 0 and w % 16 == 0) or (w == 40 and h % 4 == 0)))):
+            if pixels <= (CONV_S2_MAX_PIXELS if st == 2 else CONV3X3_MAX_PIXELS):
                 return self._hip(x, skip)
             if (st == 2 and (CONV_TILED & 2) and x.is_contiguous(memory_format=torch.channels_last)
                     and _lib.load().og_conv3x3s2_tiled_supported(n, h, w, c, self.w.shape[0])):
@@ -279,6 +267,7 @@ class _Conv:
         st = self.stride[0]
         return ((CONV_TILED & 4) and self.fused and tuple(self.w.shape[2:]) == (1, 1) and tuple(self.pad) == (0, 0)
                 and c % 64 == 0 and self.w.shape[0] % 128 == 0 and x.is_cuda
+                and x.is_contiguous(memory_format=torch.channels_last)
                 and n * ((h - 1) // st + 1) * ((w - 1) // st + 1) >= CONV_PW_MIN_PIXELS)
 
     def pointwise(self, x, x2=None, other=None, bias=True, skip=None):
@@ -294,7 +283,13 @@ class _Conv:
             wcat = wcat.contiguous()
             self.w_tiled = torch.empty(wcat.numel(), dtype=self.w.dtype, device=self.w.device)
             _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wcat), wcat.shape[1], cout, 2, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
-        assert x.is_contiguous(memory_format=torch.channels_last) and (x2 is None or (x2.shape == x.shape and x2.is_contiguous(memory_format=torch.channels_last)))
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        if x2 is not None:
+            if x2.shape != x.shape:
+                raise ValueError(f'pointwise: the second input {tuple(x2.shape)} must have the shape of the first {tuple(x.shape)}')
+            if not x2.is_contiguous(memory_format=torch.channels_last):
+                x2 = x2.contiguous(memory_format=torch.channels_last)
         if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
             skip = skip.contiguous(memory_format=torch.channels_last)
         out = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -324,14 +319,17 @@ class _Conv:
         n, c, h, w = x.shape
         return (CONV_UP2 and self.hip3x3 and self.stride[0] == 1 and (CONV_TILED & 1) and n * h * w >= CONV_TILED_MIN_PIXELS
                 and self.w.shape[0] % 128 == 0 and not _WHATIF and x.is_cuda
+                and n * h * w * 4 * self.w.shape[0] < 2 ** 30        # the (N, Cout, 2H, 2W) tensor it updates in place
                 and _lib.load().og_conv3x3_tiled_supported(n, h, w, c, self.w.shape[0]))
 
     def up2(self, x, skip, up):
         """up += nearest_x2(act(conv(x) + bias + skip)) in one launch (up: (N, Cout, 2H, 2W) channels-last, in place)."""
         n, c, h, w = x.shape
         cout = self.w.shape[0]
-        assert x.is_contiguous(memory_format=torch.channels_last) and up.is_contiguous(memory_format=torch.channels_last)
-        assert tuple(up.shape) == (n, cout, 2 * h, 2 * w)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        if tuple(up.shape) != (n, cout, 2 * h, 2 * w) or not up.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError(f'up2: `up` must be a channels-last {(n, cout, 2 * h, 2 * w)} tensor, got {tuple(up.shape)}')
         if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
             skip = skip.contiguous(memory_format=torch.channels_last)
         lib = _lib.load()
@@ -349,7 +347,8 @@ class _Conv:
     def _hip(self, x, skip):
         n, c, h, w = x.shape
         cout, st = self.w.shape[0], self.stride[0]
-        assert x.is_contiguous(memory_format=torch.channels_last)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
         if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
             skip = skip.contiguous(memory_format=torch.channels_last)
         lib = _lib.load()
@@ -385,9 +384,9 @@ class _Residual:
             self.c2.b32 = (self.c2.b32 + self.skip.b32).contiguous()
             self.c2.b = self.c2.b32.to(dtype)
             # small levels: the 1x1 projection is appended along K of conv2 (og_conv2d_proj_bf16), one launch instead
-            # of a MIOpen convolution + its output round trip
+            # of a separate 1x1 convolution + its output round trip
             if (self.c2.hip3x3 and tuple(self.c2.stride) == (1, 1) and tuple(self.skip.w.shape[2:]) == (1, 1)
-                    and self.skip.w.shape[1] % 64 == 0 and int(os.environ.get('OG_ENGINE_CONV_PROJ', '1'))):
+                    and self.skip.w.shape[1] % 64 == 0):
                 cout = self.c2.w.shape[0]
                 self.w_cat = torch.cat([self.c2.w.permute(0, 2, 3, 1).reshape(cout, -1),
                                         self.skip.w.reshape(cout, -1)], 1).contiguous()
@@ -533,59 +532,37 @@ class _Level:
         return _run(self.low3[:-1], low)
 
     def __call__(self, x):
-        if BRANCHES and x.is_cuda and BRANCH_MIN_DEPTH <= self.depth <= BRANCH_MAX_DEPTH:
+        if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None:
-                # OG_ENGINE_SIDE_PRIORITY: the trunk below is the latency-critical chain, the branch is bulk work
-                prio = int(os.environ.get('OG_ENGINE_SIDE_PRIORITY', '0'))
-                if self.depth < SIDE_SHARED:
-                    key = (x.device.index, _issuer.engine)
-                    if key not in _shared_side:
-                        _shared_side[key] = torch.cuda.Stream(x.device, priority=prio)
-                    self._side = _shared_side[key]
-                else:
-                    self._side = torch.cuda.Stream(x.device, priority=prio)
-            box = {}
-            trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST and self.depth >= BRANCH_DELAY
+                self._side = torch.cuda.Stream(x.device)
+            side, box = self._side, {}
+            trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST
             fork_ev = None
             if trunk_first:
                 fork_ev = torch.cuda.Event()
                 fork_ev.record(cur)                          # the fork point: x is complete here
 
-            def start(side=self._side, depth=self.depth, box=box):
+            def start():
                 if fork_ev is not None:
                     side.wait_event(fork_ev)                 # fork: up1 only needs x
                 else:
                     side.wait_stream(torch.cuda.current_stream(x.device))
                 outer = _issuer.branch
                 with torch.cuda.stream(side):
-                    _issuer.branch = depth + 1
+                    _issuer.branch = self.depth + 1
                     box['up'] = _run(self.up1, x)
                     _issuer.branch = outer
-                    if depth < SIDE_SHARED:
-                        box['done'] = torch.cuda.Event()
-                        box['done'].record(side)
 
-            after_first = None
-            if self.depth < BRANCH_DELAY:
-                _pending_branches.append(start)               # started when the trunk enters depth BRANCH_DELAY
-            elif trunk_first:
-                def after_first():                            # called behind the first kernel of the trunk below
-                    while _pending_branches:
-                        _pending_branches.pop(-1 if SIDE_SHARED else 0)()
+            if trunk_first:
+                low = self._lower(x, start)                  # the branch is queued behind the first kernel of the trunk below
+                if 'up' not in box:
                     start()
             else:
-                while _pending_branches:                      # (shared stream: deepest first = the order of the joins)
-                    _pending_branches.pop(-1 if SIDE_SHARED else 0)()
                 start()
-            low = self._lower(x, after_first)
-            while 'up' not in box:                            # (a delay deeper than the pyramid: start before the join)
-                _pending_branches.pop(0)()
+                low = self._lower(x)
             up = box['up']
-            if 'done' in box:
-                cur.wait_event(box['done'])                  # shared side stream: only this level's branch
-            else:
-                cur.wait_stream(self._side)                  # join before the merge
+            cur.wait_stream(side)                            # join before the merge
         else:
             low = self._lower(x)
             up = _run(self.up1, x)
@@ -651,7 +628,7 @@ class InferenceEngine:
         # GPU bf16 path: the stem (7x7 stride 2, 3 -> 128) on og_stem7x7_bf16: weight as [cout][ky][8 taps][4 channels]
         self.stem_w = None
         c0 = net.pre[0].conv
-        if (fused and int(os.environ.get('OG_ENGINE_STEM', '1')) and tuple(c0.weight.shape) == (128, 3, 7, 7)
+        if (fused and tuple(c0.weight.shape) == (128, 3, 7, 7)
                 and tuple(c0.stride) == (2, 2) and tuple(c0.padding) == (3, 3) and height % 32 == 0 and width % 32 == 0):
             w7 = self.pre[0].w.float().permute(0, 2, 3, 1)                       # (128, ky, kx, ch), BN folded
             packed = torch.zeros((128, 7, 8, 4), dtype=torch.float32, device=w7.device)
@@ -707,7 +684,8 @@ class InferenceEngine:
                     inter = self.inters[s](self.inters_[s].pointwise(inter, x2=feat, other=self.cnvs_[s]))
                 else:
                     inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
-        if self.heads_w is not None and (CONV_TILED & 4) and feat.shape[1] % 64 == 0 and len(self.head_channels) <= 4:
+        if (self.heads_w is not None and (CONV_TILED & 4) and feat.shape[1] % 64 == 0 and len(self.head_channels) <= 4
+                and feat.is_contiguous(memory_format=torch.channels_last)):
             lib = _lib.load()
             n, c, h, w = feat.shape
             if self.heads_tiled is None:
@@ -747,23 +725,16 @@ class InferenceEngine:
         return (hm, off) + extra
 
     def _capture(self):
-        # MIOpen "find" picks per-shape kernels during the warm-up passes (1.4x over the defaults here); the process-wide
-        # flag is put back afterwards
-        benchmark_before = torch.backends.cudnn.benchmark
-        torch.backends.cudnn.benchmark = True
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):                      # warm-up: MIOpen kernel selection, allocator
+            for _ in range(2):                      # warm-up: weight tiling / packing, workspaces, allocator
                 self._forward(self._static_in)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._graph = torch.cuda.CUDAGraph()
-        # (capturing the trunk on a high-priority stream, OG_ENGINE_TRUNK_PRIORITY=1, measured no difference)
-        trunk = torch.cuda.Stream(self.device, priority=-1) if int(os.environ.get('OG_ENGINE_TRUNK_PRIORITY', '0')) else None
-        with torch.no_grad(), torch.cuda.graph(self._graph, stream=trunk):
+        with torch.no_grad(), torch.cuda.graph(self._graph):
             self._out = self._forward(self._static_in)
-        torch.backends.cudnn.benchmark = benchmark_before
 
     @torch.no_grad()
     def forward_raw(self, images):

@@ -95,9 +95,10 @@ class EvalPreprocess:
         total = sum(h * w * 3 for h, w in sizes)
         stage = self._staging(total)
         o = 0
+        stage_np = stage[0].numpy()                    # (a plain memcpy: torch's copy_ into the pinned buffer ran at 0.7 GB/s)
         for im, (h, w) in zip(images, sizes):          # pack the batch into ONE pinned buffer: one H2D copy
             assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'images are (h, w, 3) uint8 RGB'
-            stage[0][o:o + h * w * 3].copy_(torch.from_numpy(np.ascontiguousarray(im)).reshape(-1))
+            np.copyto(stage_np[o:o + h * w * 3].reshape(h, w, 3), im)
             o += h * w * 3
         with torch.cuda.stream(self.copy_stream):
             # allocated on the copy stream's pool: a block of the compute stream's pool may still be in use by kernels

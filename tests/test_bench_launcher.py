@@ -39,6 +39,41 @@ def test_gpus_flag_spawns_that_many_ranks_dry_run():
     assert 'GPU_MAX_HW_QUEUES' in line['knobs'] and all(isinstance(v, str) for v in line['knobs'].values())
 
 
+def test_eight_ranks_dry_run():
+    """The 8-GPU launch of the driver (one process per GPU, reference train_dist.py:151-152), control plane only: eight gloo
+    ranks rendezvous, meet at the barriers, MAX-reduce the time and rank 0 prints the one line."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--steps', '2', '--warmup', '1', '--dry-run'],
+                       capture_output=True, text=True, timeout=600, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line['n_gpus'] == 8 and line['rccl'] == {'world': 8, 'backend': 'gloo', 'device_ids': [None] * 8}
+    assert line['elapsed_s'] >= 0.08          # MAX over ranks: rank 7 sleeps 80 ms
+
+
+def test_rank_pinning_picks_the_numa_node_of_the_gpu(monkeypatch):
+    """pin_rank: rank r of 8 goes to NUMA node r * nodes // 8 (GPUs hang off the host's nodes in device order), before any HIP
+    call; one node, one rank or OG_BENCH_NUMA=0 leave the affinity alone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    have = sorted(os.sched_getaffinity(0))
+    half = max(1, len(have) // 2)
+    nodes = [(0, have[:half]), (1, have[half:] or have[:half])]
+    monkeypatch.setattr(bench, 'numa_nodes', lambda: nodes)
+    pinned = []
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus: pinned.append(sorted(cpus)))
+    assert bench.pin_rank(0, 8) == {'node': 0, 'cpus': len(nodes[0][1])} and pinned[-1] == sorted(nodes[0][1])
+    assert bench.pin_rank(3, 8)['node'] == 0 and bench.pin_rank(4, 8)['node'] == 1 and bench.pin_rank(7, 8)['node'] == 1
+    n = len(pinned)
+    assert bench.pin_rank(0, 1) is None and len(pinned) == n               # one rank: nothing to separate
+    monkeypatch.setenv('OG_BENCH_NUMA', '0')
+    assert bench.pin_rank(5, 8) is None and len(pinned) == n
+    monkeypatch.delenv('OG_BENCH_NUMA')
+    monkeypatch.setattr(bench, 'numa_nodes', lambda: nodes[:1])
+    assert bench.pin_rank(5, 8) is None and len(pinned) == n               # one node
+
+
 def test_a_rank_that_dies_fails_the_whole_job_quickly():
     """A rank-local failure must surface as a non-zero exit of `bench.py --gpus N`, not as peers waiting at the barrier."""
     import time

@@ -1,10 +1,10 @@
-"""og_generate_limbs_f32 -- joint_dets + limb pairing in ONE call (decoder/heatmap.py:15-59 + decoder/collect.py:62-236),
-both as the persistent single-launch kernel (OG_LIMBS_SINGLE_LAUNCH) and as two queued launches (flags 0: band top-k, merge + pairing) -- through the
-C ABI, against the oracle and against the separate entry points (og_nms_topk_f32 + og_collect_limbs_full_f32).
+"""og_generate_limbs_f32 -- joint_dets + limb pairing in ONE call (decoder/heatmap.py:15-59 + decoder/collect.py:62-236): two queued
+launches (band top-k; merge + pairing) -- through the C ABI, against the oracle and against the separate entry points
+(og_nms_topk_f32 + og_collect_limbs_full_f32).
 
 Bit-exact candidate lists (scores, flat indices) and limb rows; the limb score within 1e-4 of the oracle (the device exp()).
-The in-launch hand-off (sc1 stores -> ticket -> sc1 loads) is exercised under repetition, with workspace reuse across
-shapes (persistent kernel and fallback shapes interleaved) and on the full bs8 640x640 batch."""
+Exercised under repetition, with workspace reuse across shapes (shapes whose merge stage takes the fallback interleaved) and on
+the full bs8 640x640 batch."""
 import numpy as np
 import pytest
 import torch
@@ -27,7 +27,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def run_single(hr, off, k, dev, ws=None, want_lists=True, thre=0.04, min_len=0.5, off_lowres=True, single=True):
+def run_single(hr, off, k, dev, ws=None, want_lists=True, thre=0.04, min_len=0.5, off_lowres=True, single=0):
     """-> limbs (N,L,k,13), scores (N,C,k), inds (N,C,k), workspace"""
     lib = _lib.load()
     n, c, h, w = hr.shape
@@ -71,7 +71,7 @@ def maps(seed, n, h, w, dev, persons=4):
 
 @pytest.mark.parametrize("n,size,k", [(2, (256, 256), 32), (1, (640, 640), 32), (3, (384, 512), 48), (2, (128, 640), 16),
                                        (8, (256, 256), 64), (1, (64, 64), 9), (5, (512, 256), 1),
-                                       (2, (320, 320), 100)])   # k > 64: the persistent kernel declines, both flags run the two launches
+                                       (2, (320, 320), 100)])
 def test_single_launch_matches_oracle_and_three_launch(dev, n, size, k):
     hr, off, t_hr, t_off = maps(500 + n + k, n, size[0], size[1], dev)
     limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev)
@@ -83,15 +83,9 @@ def test_single_launch_matches_oracle_and_three_launch(dev, n, size, k):
     assert torch.equal(l3, limbs) and torch.equal(s3, sc) and torch.equal(i3, ix)      # same code, same bits
     l_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False)             # lists optional
     assert torch.equal(l_only, limbs)
-    l0, s0, i0, _ = run_single(t_hr, t_off, k, dev, single=False)                   # flags 0: band top-k + merge-and-pair kernel behind one call
-    assert torch.equal(l0, limbs) and torch.equal(s0, sc) and torch.equal(i0, ix)
-    l0_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False, single=False)
-    assert torch.equal(l0_only, limbs)
-    l2, s2, i2, w2 = run_single(t_hr, t_off, k, dev, single=_lib.OG_LIMBS_TAIL_IN_BAND)   # merge + pairing by last arrivers of the band launch
-    assert torch.equal(l2, limbs) and torch.equal(s2, sc) and torch.equal(i2, ix)
-    assert int(w2[:61440].view(torch.int32).abs().sum()) == 0, "tickets not returned to zero"
-    l2_only, _, _, _ = run_single(t_hr, t_off, k, dev, want_lists=False, single=_lib.OG_LIMBS_TAIL_IN_BAND)
-    assert torch.equal(l2_only, limbs)
+    again, s_again, i_again, w2 = run_single(t_hr, t_off, k, dev)                     # a second call on a fresh workspace: same bits
+    assert torch.equal(again, limbs) and torch.equal(s_again, sc) and torch.equal(i_again, ix)
+    assert int(w2[:61440].view(torch.int32).abs().sum()) == 0, "the reserved head of the workspace must stay zero"
 
 
 def test_degenerate_planes(dev):
@@ -111,14 +105,13 @@ def test_degenerate_planes(dev):
     assert (sc.cpu().numpy() == rs).all() and (ix.cpu().numpy() == ri).all()
     l3, _, _ = run_three(t_hr, t_off, k, dev)
     assert torch.equal(l3, limbs)
-    for flags in (0, _lib.OG_LIMBS_TAIL_IN_BAND):   # the zero-filler rule in the merge kernel / in the band launch's tail
-        lf, sf, xf, _ = run_single(t_hr, t_off, k, dev, single=flags)
-        assert torch.equal(lf, limbs) and torch.equal(sf, sc) and torch.equal(xf, ix)
+    lf, sf, xf, _ = run_single(t_hr, t_off, k, dev)   # the zero-filler rule in the merge kernel, again
+    assert torch.equal(lf, limbs) and torch.equal(sf, sc) and torch.equal(xf, ix)
 
 
 def test_workspace_reuse_across_shapes_and_fallback(dev):
-    """One zero-filled workspace, many calls: persistent-kernel shapes, fallback shapes (k > 64, W % 4 != 0, tiny planes)
-    and back -- the ticket area must come back to zero after every call."""
+    """One zero-filled workspace, many calls: large shapes, shapes that take other paths (k > 64, W % 4 != 0, tiny planes) and
+    back -- the reserved head of the workspace stays zero, every call finds the workspace ready."""
     lib = _lib.load()
     seq = [(2, 256, 256, 32), (1, 96, 128, 100), (2, 256, 256, 32), (1, 40, 50, 8), (3, 128, 128, 48), (1, 16, 16, 4),
            (2, 256, 256, 32)]
@@ -132,14 +125,12 @@ def test_workspace_reuse_across_shapes_and_fallback(dev):
             hr = synth.noise_batch(700 + j, (n, 17, h, w)) - 0.3
             off = synth.noise_batch(800 + j, (n, 38, h, w)) * 5
             t_hr, t_off, off_lr = torch.from_numpy(hr).to(dev), torch.from_numpy(off).to(dev), False
-        limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev, ws=ws, off_lowres=off_lr,
-                                      single=(1, 2, 1, 2, 0, 2, 1)[j])   # all three forms share the workspace
+        limbs, sc, ix, _ = run_single(t_hr, t_off, k, dev, ws=ws, off_lowres=off_lr)
         rs, ri, _, _ = oracle.nms_topk(hr, k)
         assert (sc.cpu().numpy() == rs).all() and (ix.cpu().numpy() == ri).all(), (j, n, h, w, k)
         ref = oracle.collect_limbs(rs, ri, off, off_lr, (h, w), SK, 0.04, 0.5)
         assert_limbs_match(ref, limbs.cpu().numpy(), 1e-4)
-        assert int(ws[:61440].view(torch.int32).abs().sum()) == 0, "tickets not returned to zero"
-        assert int(ws[61440:65536].view(torch.int32)[1]) == 0, "stream-done ticket not returned to zero"
+        assert int(ws[:65536].view(torch.int32).abs().sum()) == 0, "the reserved head of the workspace must stay zero"
 
 
 def test_full_size_batch_repeated(dev):
@@ -181,16 +172,16 @@ def test_errors(dev):
     jf, jt = _lib.int_table(JF, dev), _lib.int_table(JT, dev)
     ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
     rc = lib.og_generate_limbs_f32(_lib.ptr(t), _lib.ptr(o), 1, 2, None, 0, None, 0, 1, 17, 64, 64, _lib.ptr(jf), _lib.ptr(jt),
-                                   19, 32, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs), 1, _lib.ptr(ws), ws.numel(), None)
+                                   19, 32, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs), 0, _lib.ptr(ws), ws.numel(), None)
     assert rc == _lib.OG_ENOSPC and b"workspace" in lib.og_last_error()
     rc = lib.og_generate_limbs_f32(_lib.ptr(t), _lib.ptr(o), 1, 3, None, 0, None, 0, 1, 17, 64, 64, _lib.ptr(jf), _lib.ptr(jt),
-                                   19, 32, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs), 1, _lib.ptr(ws), ws.numel(), None)
+                                   19, 32, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs), 0, _lib.ptr(ws), ws.numel(), None)
     assert rc == _lib.OG_EUNSUPPORTED
 
 
 def test_random_shapes_all_forms_agree(dev):
-    """Random (N, H, W, k) incl. degenerate planes: flags 0 (band + merge-and-pair), SINGLE_LAUNCH and TAIL_IN_BAND against the
-    separate entry points, bit for bit, tickets back at zero."""
+    """Random (N, H, W, k) incl. degenerate planes: og_generate_limbs_f32 (band top-k + merge-and-pair) against the separate
+    entry points, bit for bit; a reserved `flags` value changes nothing."""
     rng = np.random.default_rng(7)
     done = 0
     for it in range(40):
@@ -204,7 +195,7 @@ def test_random_shapes_all_forms_agree(dev):
         off = (synth.noise_batch(2000 + it, (n, 38, h // 4, w // 4)) * 6).astype(np.float32)
         t_hr, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
         l3, s3, i3 = run_three(t_hr, t_off, k, dev)
-        for flags in (0, _lib.OG_LIMBS_SINGLE_LAUNCH, _lib.OG_LIMBS_TAIL_IN_BAND):
+        for flags in (0, 3):
             l, s, i, ws = run_single(t_hr, t_off, k, dev, single=flags)
             assert torch.equal(l, l3) and torch.equal(s, s3) and torch.equal(i, i3), (it, n, h, w, k, flags)
             assert int(ws[:61440].view(torch.int32).abs().sum()) == 0, (it, flags)

@@ -283,6 +283,37 @@ def test_flip_merge_exact(dev, name):
     assert (mh.cpu().numpy() == rh).all() and (mo.cpu().numpy().ravel() == ro.ravel()).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 256), (8, 640, 640), (3, 384, 512)])
+def test_flip_fold_equals_flip_merge(dev, shape):
+    """flip_augment folded into its consumers (og_upsample_bicubic4_flip_f32, og_generate_limbs_flip_f32: the merge of
+    decoder/factory.py:98-146 computed on the loads) == og_flip_merge_f32 followed by the plain kernels, bit for bit: the hi-res
+    heatmaps, the limbs (every column) and the poses; and the folded pipeline against the oracle on two images."""
+    n, h, w = shape
+    hm, off = synth.synth_batch(31 + n, n, h, w, flip=True)
+    t_hm, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+    proc = processor(n)
+    assert proc.fold_flip
+    kp_perm, (limb_perm, reserve) = proc.keypoints_flips, proc.limbs_flips
+    mh, _, mo, _, _ = proc.flip_augment(t_hm, [], t_off, [], False, 2)
+    hr_ref = decoder.factory.upsample4(mh, 'bicubic')
+    hr = decoder.factory.upsample4_flip(t_hm, kp_perm)
+    assert torch.equal(hr, hr_ref)
+    keep = [1 if l in reserve else 0 for l in range(len(limb_perm))]
+    l_ref = proc.limb_collect.generate_limbs_lowres(hr_ref, mo)
+    l_fold = proc.limb_collect.generate_limbs_flip(hr, t_off, limb_perm, keep)
+    assert torch.equal(l_fold, l_ref)
+    feats = [([None, t_hm], [[], []], [[], []]), ([None, t_off], [[], []], [[], []])]
+    poses_fold = proc.generate_poses(feats, flip_test=True)
+    proc.fold_flip = False
+    poses_ref = proc.generate_poses(feats, flip_test=True)
+    assert len(poses_fold) == len(poses_ref) == n and all(np.array_equal(a_, b_) for a_, b_ in zip(poses_fold, poses_ref))
+    sel = [0, 1, n, n + 1]
+    ref, _ = oracle.decode(hm[sel], off[sel], cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                           min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
+                           flip=flip_tables())
+    assert_poses_match(ref, poses_fold[:2], SCORE_TOL)
+
+
 @pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat"])
 def test_collect_limbs_4d_offsets_hires_form(dev, name):
     """The reference's own call (collect.py:62 with vector_nd=4 on materialised hi-res offsets) == low-res sampling."""
@@ -431,8 +462,12 @@ def test_submit_handles_outstanding(dev, order):
     assert len(pools[0]) == 4
     for h, r in zip(more, refs[:2]):
         assert all((x == y).all() for x, y in zip(r, h.result()))
-    dropped = proc.submit(features(*batches[3], dev))     # a handle dropped unread frees its slot as well
-    del dropped
+    dropped = proc.submit(features(*batches[3], dev))     # a handle dropped unread gives its slot back as well: at once if its copy
+    del dropped                                            # has landed, else at the first submit() after that (no wait in __del__)
+    torch.cuda.synchronize()
+    last = proc.submit(features(*batches[0], dev))
+    assert len(pools[0]) == 4 and sum(sl.busy for sl in pools[0]) == 1
+    assert all((x == y).all() for x, y in zip(refs[0], last.result()))
     assert not any(sl.busy for sl in pools[0])
 
 
@@ -449,6 +484,47 @@ def test_generate_poses_nonsquare_vs_oracle(dev, size, batch, k, flip):
         proc.fused_upsample = fused
         assert_poses_match(ref, proc.generate_poses(feats, flip_test=flip), SCORE_TOL)
         assert_poses_match(ref, proc.submit(feats, flip_test=flip).result(), SCORE_TOL)
+
+
+@pytest.mark.parametrize("kernel", [1, 5, 7])
+def test_hmp_nms_other_windows(dev, kernel):
+    """hmp_NMS accepts any odd window like the reference (decoder/heatmap.py:15-35); 3 is the HIP kernel, the others run the
+    reference's ops on the device: same result as those ops on the CPU, and window 3 through both routes agrees."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(kernel)
+    heat = torch.randn(2, 3, 37, 53, generator=g)
+    heat[0, 0, 5:9, 5:9] = 2.0                     # a plateau
+    heat[1, 1] = -heat[1, 1].abs()                 # a negative plane (zero padding wins on the border)
+    pad = (kernel - 1) // 2
+    ref = heat * (F.max_pool2d(F.pad(heat, [pad] * 4), (kernel, kernel), stride=1) == heat).float()
+    got = decoder.hmp_NMS(heat.to(dev), kernel).cpu()
+    assert torch.equal(got, ref) and torch.equal(torch.signbit(got), torch.signbit(ref))
+    ref3 = heat * (F.max_pool2d(F.pad(heat, [1] * 4), (3, 3), stride=1) == heat).float()
+    assert torch.equal(decoder.hmp_NMS(heat.to(dev)).cpu(), ref3)
+    with pytest.raises(RuntimeError):
+        decoder.hmp_NMS(heat.to(dev), 4)           # even window: shapes no longer match, as in the reference
+
+
+def test_global_indices_beyond_2_pow_24(dev):
+    """1024x1024 inputs: C * H * W = 17.8 M > 2^24, so the GLOBAL peak indices the limbs carry as fp32 (reference
+    decoder/collect.py:194-199,227-228: `ind + jtype * h * w` cast to float) are rounded to even for the upper channels, and the
+    grouping compares the rounded values (group.py:87-109).  The reference rounds the same way, so parity is well defined: the
+    HIP pipeline must reproduce the oracle bit for bit there too -- limbs (every column) and poses."""
+    hm, off = synth.synth_batch(11, 1, 1024, 1024, n_persons=14)
+    assert hm.shape == (1, 17, 256, 256)
+    proc = processor(1)
+    feats = features(hm, off, dev)
+    limbs = proc.generate_limbs(feats).cpu().numpy()
+    ref_poses, mid = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+                                   min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"])
+    assert_limbs_match(mid["limbs"], limbs, SCORE_TOL, valid_only_thre=FLAGS["thre_hmp"])
+    valid = (limbs[..., 2] >= FLAGS["thre_hmp"]) & (limbs[..., 5] >= FLAGS["thre_hmp"])
+    ind = limbs[..., 6:8][valid]
+    assert (ind >= 2 ** 24).any(), 'the case must reach the rounded index range'
+    assert (ind[ind >= 2 ** 24] % 2 == 0).all()          # fp32 spacing is 2 there: odd indices do not exist
+    poses = proc.generate_poses(feats)
+    assert_poses_match(ref_poses, poses, SCORE_TOL)
+    assert len(poses[0]) >= 5
 
 
 def test_full_size_batch_properties(dev):

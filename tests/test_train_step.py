@@ -165,6 +165,44 @@ def test_bench_mode_prints_one_json_line_cpu(tmp_path, monkeypatch, capsys):
     assert os.listdir(tmp_path) == []                            # no checkpoint in bench mode
 
 
+def _bench8_worker(rank, world, port, tmp, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    import contextlib
+    import io
+    import json
+    torch.set_num_threads(1)
+    from offsetguided_amd import models, train_dist
+    models.model_factory = lambda args: (TinyNet(), _criterion())
+    torch.cuda.is_available = lambda: False
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        train_dist.main(['--no-pretrain', '--square-length', '64', '--batch-size', '2', '--checkpoint-path', tmp, '--bench',
+                         '--bench-steps', '2', '--bench-warmup', '1', '--lambdas', '1', '0', '0', '100', '0.01'])
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith('{')]
+    q.put((rank, json.loads(lines[0]) if lines else None))
+
+
+def test_bench_mode_eight_ranks_gloo(tmp_path):
+    """BASELINE configs[4]'s bring-up (reference train_dist.py:151-152, 238-239) with EIGHT ranks on the CPU stand-in model over
+    gloo: DDP steps, the stand-alone gradient all-reduce measurement, and exactly one JSON line (rank 0) for the whole job."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench8_worker, args=(r, 8, port, str(tmp_path), q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0] is not None and all(got[r] is None for r in range(1, 8))
+    d = got[0]
+    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['value'] > 0
+    assert d['grad_allreduce']['bus_GBps'] is not None and d['grad_allreduce']['ms'] > 0      # (a tiny payload: the rate rounds to 0.0)
+    assert d['rccl']['world'] == 8 and d['rccl']['backend'] == 'gloo'
+
+
 @pytest.mark.gpu
 def test_gpu_train_bench_line():
     """train_dist --bench on the GPU (BASELINE configs[4] hook, one rank): the full Hourglass-104 step at 256x256 bs2."""

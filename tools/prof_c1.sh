@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes for C1 (the 160x160 256->256 layer) on the GPU box: one counter group per rocprofv3 --pmc pass, the program
-# directly after `--`, no trace domains mixed in.  usage: tools/prof_c1.sh <out dir under gpurun_out> [extra bench args]
+# directly after `--`, every --pmc pass carries --kernel-trace only (no other trace domain).  usage: tools/prof_c1.sh <out dir under gpurun_out> [extra bench args]
 set -u
 out=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
