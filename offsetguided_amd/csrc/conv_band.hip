@@ -159,9 +159,14 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool cw = wave < kWaves;                 // compute wave (else loader wave)
-    const int ltid = tid - kWaves * 64;            // loader thread 0 .. 255
-    const int lwave = wave - kWaves;
+    // CHAIN: eight waves with fixed parts (above).  One layer per launch: FOUR waves that play both parts one after the other --
+    // nothing is prefetched there, and a 4-wave workgroup (one wave per SIMD, <= 256 registers) can share its CU with a
+    // workgroup of the kernels that run beside it in the network (the 8-wave form owns the CU: every such launch then waits
+    // for the 20x20 convolution of the up1 branch beside it, +0.2 ms per forward)
+    const bool cw = CHAIN ? wave < kWaves : true;              // compute wave
+    const bool lw = CHAIN ? wave >= kWaves : true;             // loader wave
+    const int ltid = CHAIN ? tid - kWaves * 64 : tid;          // loader thread 0 .. 255
+    const int lwave = CHAIN ? wave - kWaves : wave;
     const int nch = a.Cin >> 5, nch2 = a.Cin2 >> 5;
     const int img = item / a.bands, band = item - img * a.bands;
     const int y0 = band * a.band_rows, rows = min(a.band_rows, a.H - y0);
@@ -172,7 +177,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     const bool x_chain = CHAIN && (a.in_chain & 1), skip_chain = CHAIN && (a.in_chain & 2), x2_chain = CHAIN && (a.in_chain & 4);
     const bool has_proj = KW2 > 0 && a.x2 != nullptr;
 #ifdef OG_BAND_STAMPS
-#define LSTAMP(i) do { if (stamps && tid == kWaves * 64) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LSTAMP(i) do { if (stamps && ltid == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define CSTAMP(i) do { if (stamps && tid == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define LSTAMP(i) do { } while (0)
@@ -180,7 +185,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
 #endif
     LSTAMP(0);
 
-    if (!cw) {
+    if (lw) {
         // ---- zero pixels of the LDS image: the leading pixel, the pixel behind every row, the rows outside the image
         const int slots = a.pitch >> 4;            // 16-byte slots per pixel
         for (int s = ltid; s < (NR + 1) * slots; s += kWaves * 64) {
@@ -212,7 +217,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     if (CHAIN && wait_word) lds_barrier();
     LSTAMP(1);
 
-    if (!cw) {
+    if (lw) {
         // ---- activations: whole pixels, one per wave instruction (Cin / 8 <= 64 lanes x 16 B), into the padded LDS image
         {
             const int r_lo = max(ri0, 0), r_hi = min(ri0 + NR - 1, a.Hin - 1);      // input rows that exist
@@ -395,7 +400,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
 }
 
 template <int PT, int KW, int KW2>
-__global__ void __launch_bounds__(2 * kWaves * 64)
+__global__ void __launch_bounds__(kWaves * 64)
 conv_band_kernel(BandLayer a, unsigned long long *stamps)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -404,7 +409,7 @@ conv_band_kernel(BandLayer a, unsigned long long *stamps)
     const int items = a.N * a.bands;
     const int g = wid / items;
     u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
-    if (threadIdx.x < kWaves * 64) band_load_weights<KW, KW2>(a, g, wf, wp);
+    band_load_weights<KW, KW2>(a, g, wf, wp);
     band_role<PT, KW, KW2, false>(a, g, wid - g * items, wf, wp, lds, nullptr, 0, nullptr, nullptr,
                                   stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr, [](int) {}, [] {});
 }
@@ -725,7 +730,7 @@ OG_API int OG_LP_NAME(og_conv_band)(const void *x, const void *w_packed, const f
         if (attr_.need())                                                                                             \
             (void)hipFuncSetAttribute((const void *)conv_band_kernel<PT_, KW_, KW2_>,                                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);                           \
-        hipLaunchKernelGGL((conv_band_kernel<PT_, KW_, KW2_>), dim3((unsigned)p.grid), dim3(2 * 64 * kWaves), p.lds_bytes, st, a, stamps); \
+        hipLaunchKernelGGL((conv_band_kernel<PT_, KW_, KW2_>), dim3((unsigned)p.grid), dim3(64 * kWaves), p.lds_bytes, st, a, stamps); \
     } while (0)
     BAND_DISPATCH(BAND_LAUNCH, p.pt, a.kw, a.kw2);
 #undef BAND_LAUNCH

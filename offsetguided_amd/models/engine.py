@@ -5,8 +5,9 @@ What this file adds to the eager module is the shape the hardware wants:
   * fp16 (default: the reference's apex-O2 arithmetic) or bf16 activations / weights in channels-last (NHWC) layout;
   * EVERY convolution on a hand-written MFMA kernel, bias + ReLU + residual add fused into its epilogue, fp32 accumulation:
     og_conv3x3_tiled_* / og_conv3x3s2_tiled_* / og_conv1x1_tiled_* for the 160x160 ... 20x20 levels (two 4-wave workgroups
-    per CU, pre-tiled weights), the split-K kernel og_conv2d_* / og_conv2d_proj_* for 10x10 / 5x5 and the stride-2 / projection
-    layers there (optionally the band-resident og_conv_band_*), og_stem7x7_* for the stem, og_conv1x1_heads_* for the heads;
+    per CU, pre-tiled weights), the band-resident og_conv_band_* (K split inside a workgroup, no slabs) for 10x10 / 5x5, the
+    split-K kernel og_conv2d_* / og_conv2d_proj_* for the stride-2 / projection layers at 20x20 and whatever the band kernel does
+    not serve, og_stem7x7_* for the stem, og_conv1x1_heads_* for the heads;
     a shape none of them serves falls back to torch's convolution + one og_bias_act_* pass;
   * the hourglass merges (nearest x2 upsample + add) on the epilogue of the convolution below them where that kernel is the
     tiled one, else one og_upsample2_add_* pass;
@@ -23,7 +24,8 @@ train / eval flag and device stay as they are.
 Environment switches (read at import; the measured-best value is the default): OG_CONV_TILED (7: bit 0 / 1 / 2 = 3x3 stride 1 /
 3x3 stride 2 / 1x1 layers on the tiled kernels), OG_CONV_UP2 (1: merges on the producing convolution's epilogue),
 OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (1: capture order at the forks of
-depth >= 1), OG_CONV_BAND_MAX_PIXELS (0) / OG_CONV_BAND_CHAIN (0): the band-resident kernel, OG_ENGINE_WHATIF (timing diagnosis,
+depth >= 1), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024) /
+OG_CONV_BAND_CHAIN (0): the band-resident kernel for 10x10 / 5x5, OG_ENGINE_WHATIF (timing diagnosis,
 wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
 EXPERIMENTS.md and no longer exist as switches.
 """
@@ -80,15 +82,15 @@ CONV_S2_MAX_PIXELS = 4096
 CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))
 CONV_PW_MIN_PIXELS = 8192        # 1x1 layers below this stay on torch's convolution (the deep projections ride on conv2 instead)
 CONV_TILED_MIN_PIXELS = 2048     # 20x20 at batch 8 = 3 200 pixels: 20 x 4 tiles split along K
-# OG_CONV_BAND_MAX_PIXELS = P (default 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with at
-# most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: K split over the waves of a
-# workgroup, no slabs / tickets) where it serves the shape -- 1024 = the 10x10 / 5x5 levels at batch 8 -- and with
-# OG_CONV_BAND_CHAIN=1 runs of such residual blocks go out as ONE chained launch (og_conv_band_chain_*).  Measured (round 4,
-# EXPERIMENTS.md): a 5x5 layer alone 12.5 -> 8.2 us (7.4 chained), a 10x10 layer 13.7 -> 11.7, and the whole step 1-4 % SLOWER:
-# a band workgroup owns its CU (8 waves x ~240 registers), so the up1 branches that run beside the bottom of the hourglass
-# wait for it instead of sharing the chip, and a chained launch holds all 256 CUs for its ~100 us.  Off by default; the kernels,
-# their tests and tools stay (the split-K kernel keeps these layers).
-CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '0'))
+# OG_CONV_BAND_MAX_PIXELS = P (default 1024; 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with
+# at most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: one 4-wave workgroup per (image,
+# row band, 16 output channels), K split over its waves, partial tiles summed in LDS -- no fp32 slabs, no tickets) where it serves
+# the shape: 1024 = the 10x10 / 5x5 levels at batch 8.  With OG_CONV_BAND_CHAIN=1 (default 0) runs of such residual blocks go out
+# as ONE chained persistent launch (og_conv_band_chain_*).  Measured (round 4, EXPERIMENTS.md): a 5x5 layer alone 12.4 -> 8.2 us
+# (7.4 chained), a 10x10 layer 13.7 -> 11.7; in the network the 4-wave kernel is worth 1.3 % of the step TOGETHER with
+# OG_ENGINE_DEEP_SHARED=3 (each alone: nothing), the chained launch costs 1-4 % (it holds all 256 CUs for its ~100 us, the up1
+# branches that run beside the bottom of the hourglass wait for it instead of sharing the chip).
+CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '1024'))
 CONV_BAND_CHAIN = int(os.environ.get('OG_CONV_BAND_CHAIN', '0'))
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
@@ -102,6 +104,11 @@ BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fo
 # then waits across queues for the trunk (11 us in the forward timeline).  Trunk first: the trunk keeps its queue through forks
 # and merges, a fork costs it ~6 us instead (the release behind the fork point).
 TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
+# OG_ENGINE_DEEP_SHARED = D (default 3; 0 = off): the up1 branches of the levels of depth >= D share ONE side stream, in the order
+# the trunk forks them (depth 3, then depth 4): the graph executor otherwise puts the inner branches on one hardware queue DEEPEST
+# first, so the 20x20 branch of depth 3 -- ready when the trunk enters depth 3 -- only starts behind the 10x10 branch of depth 4
+# and the trunk waits for it at the depth-3 merge.  A/B over three runs: 6.02 -> 5.95 ms with the band kernel, D = 2 / 4 lose.
+DEEP_SHARED = int(os.environ.get('OG_ENGINE_DEEP_SHARED', '3'))
 CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
 _chain_ws = {}
 _conv_ws = {}
@@ -535,7 +542,12 @@ class _Level:
         if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(x.device)
+                if DEEP_SHARED and self.depth >= DEEP_SHARED:
+                    if getattr(_issuer, 'deep_side', None) is None or _issuer.deep_side[0] != (x.device.index, _issuer.engine):
+                        _issuer.deep_side = ((x.device.index, _issuer.engine), torch.cuda.Stream(x.device))
+                    self._side = _issuer.deep_side[1]
+                else:
+                    self._side = torch.cuda.Stream(x.device)
             side, box = self._side, {}
             trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST
             fork_ev = None
@@ -553,6 +565,9 @@ class _Level:
                     _issuer.branch = self.depth + 1
                     box['up'] = _run(self.up1, x)
                     _issuer.branch = outer
+                    if DEEP_SHARED and self.depth >= DEEP_SHARED:     # a shared stream: join THIS branch, not what follows it
+                        box['done'] = torch.cuda.Event()
+                        box['done'].record(side)
 
             if trunk_first:
                 low = self._lower(x, start)                  # the branch is queued behind the first kernel of the trunk below
@@ -562,7 +577,10 @@ class _Level:
                 start()
                 low = self._lower(x)
             up = box['up']
-            cur.wait_stream(side)                            # join before the merge
+            if 'done' in box:
+                cur.wait_event(box['done'])
+            else:
+                cur.wait_stream(side)                        # join before the merge
         else:
             low = self._lower(x)
             up = _run(self.up1, x)

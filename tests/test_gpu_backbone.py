@@ -796,11 +796,12 @@ def test_engine_f16_matches_reference_golden(dev):
 
 
 @pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"},
-                                   {"OG_CONV_BAND_MAX_PIXELS": "1024"}, {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}])
+                                   {"OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"}, {"OG_ENGINE_DEEP_SHARED": "2"},
+                                   {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}])
 def test_engine_schedule_knobs(dev, knobs):
     """The engine's kept A/B switches (read at import): merges as their own launches instead of on the producing convolution's
-    epilogue, up1 branch captured before the trunk below the fork, the small levels on the band-resident kernel (one launch per
-    layer / chained launches) -- the graph-engine tests again in a child process."""
+    epilogue, up1 branch captured before the trunk below the fork, the small levels back on the split-K kernel with every up1
+    branch on its own stream, the inner branches sharing a stream from depth 2, the band kernel as chained launches -- the graph-engine tests again in a child process."""
     import os
     import subprocess
     import sys
