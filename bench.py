@@ -400,18 +400,23 @@ def main():
             timed(conv_once, 5)
             # the chip lowers its clock under sustained MFMA load (MI355X_MICROARCH.md "DVFS give-back"): a 3-launch burst from an
             # idle chip runs at a higher clock than the 30 back-to-back launches the figure is quoted on -- both are reported,
-            # with the shader clock sysfs shows before and after (best effort: absent on boxes that hide it)
+            # with the shader clock level sysfs marks on the idle chip and in the middle of 60 queued launches (best effort: None on boxes
+            # that hide it)
             time.sleep(0.25)
             burst_us = timed(conv_once, 3) * 1e3
-            sclk_before = current_sclk_mhz()
+            sclk_idle = current_sclk_mhz()
             conv_us = timed(conv_once, 30) * 1e3
-            sclk_after = current_sclk_mhz()
+            for i in range(60):      # ~14 ms of queued launches: the clock level sysfs marks while they run
+                conv_once(i)
+            time.sleep(0.006)
+            sclk_load = current_sclk_mhz()
+            torch.cuda.synchronize(dev)
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
                 'kernel': 'C1 = og_conv3x3_tiled_' + a.dtype + ' (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
                           '256->256 layer, residual + bias + ReLU epilogue fused',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
-                'us_per_launch_burst_of_3': round(burst_us, 1), 'sclk_mhz_before_after': [sclk_before, sclk_after],
+                'us_per_launch_burst_of_3': round(burst_us, 1), 'sclk_mhz_idle_and_under_load': [sclk_idle, sclk_load],
                 'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
                 'frac': round(conv_flop / (conv_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 'algorithmic_flop_per_launch': conv_flop}

@@ -697,6 +697,9 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
     h.Hin = H; h.Win = W; h.stride = 1; h.taps = 9;
     h.x_bytes = (int)(M * Cin * 2);
     h.w_bytes = Cout * 9 * Cin * 2;
+#ifdef OG_TILED_STAMPS
+    h.stamps = g_stamps;
+#endif
     hipStream_t st = (hipStream_t)stream;
     const long items = tiled_items(kind, N, H, W, Cout);
     h.ksplit = (items <= (long)kMaxTiles) ? tiled_ksplit(kind, items, Cin) : 1;
@@ -721,7 +724,10 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
     } while (0)
     // VAR 2 = LDS-DMA issue behind the fragment reads (measured best; the other tuning variants -- weight-fragment prefetch,
     // 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only ablations -- are described in EXPERIMENTS.md)
-    if (kind == 1) TILED_LAUNCH(16, 16, 4, 2);
+#ifndef OG_TILED_VAR16
+#define OG_TILED_VAR16 2
+#endif
+    if (kind == 1) TILED_LAUNCH(16, 16, 4, OG_TILED_VAR16);
     else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
     else TILED_LAUNCH(40, 4, 2, 2);
 #undef TILED_LAUNCH
