@@ -818,6 +818,9 @@ static int pw_fill(const char *name, PwArgs &a, const void *x1, int C1, int H1, 
     a.x2_bytes = x2 ? (int)((long)N * H2 * W2 * C2 * 2) : 0;
     a.w_bytes = Cout * (a.C1 + a.C2) * 2;
     a.n_tiles = Cout / bn;
+#ifdef OG_PW_STAMPS
+    a.stamps = g_stamps;
+#endif
     return OG_OK;
 }
 
@@ -831,9 +834,18 @@ OG_API int OG_LP_NAME(og_conv1x1_tiled)(const void *x1, int C1, int H1, int W1, 
     const int rc = pw_fill(name, a, x1, C1, H1, W1, stride1, x2, C2, H2, W2, stride2, w_packed, bias, N, H, W, Cout, 128);
     if (rc != OG_OK) return rc;
     a.skip = (const unsigned short *)skip; a.out = (unsigned short *)out; a.relu = relu;
-    constexpr int lds_ = 3 * 2 * 128 * 64;
+    constexpr int lds_ = 256 * (2 * 128 + 16);     // the output tile's staging (68 KiB) > the weight ring (48 KiB); two workgroups per CU
+    static_assert(lds_ >= 3 * 2 * 128 * 64 && 2 * lds_ <= 160 * 1024, "LDS");
+    static OgAttrOnce attr_;
+    if (attr_.need()) {
+        (void)hipFuncSetAttribute((const void *)conv1x1_tiled_kernel<128, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+        (void)hipFuncSetAttribute((const void *)conv1x1_tiled_kernel<128, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+    }
     const long blocks = (long)((a.M + 255) / 256) * a.n_tiles;
-    hipLaunchKernelGGL((conv1x1_tiled_kernel<128, 0>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
+    if (((a.C1 + a.C2) >> 6) % 2 == 0)     // two pixel register sets in turn: an even number of 64-channel steps
+        hipLaunchKernelGGL((conv1x1_tiled_kernel<128, 0, 2>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv1x1_tiled_kernel<128, 0, 1>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -861,7 +873,10 @@ OG_API int OG_LP_NAME(og_conv1x1_heads)(const void *x, int C, const void *w_pack
     OG_REQUIRE(c <= Cout, OG_EINVAL, "%s: the heads have %d channels, the packed weight %d", name, c, Cout);
     constexpr int lds_ = 3 * 2 * 64 * 64;
     const long blocks = (long)((a.M + 255) / 256) * a.n_tiles;
-    hipLaunchKernelGGL((conv1x1_tiled_kernel<64, 1>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
+    if ((a.C1 >> 6) % 2 == 0)
+        hipLaunchKernelGGL((conv1x1_tiled_kernel<64, 1, 2>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv1x1_tiled_kernel<64, 1, 1>), dim3((unsigned)blocks), dim3(256), lds_, (hipStream_t)stream, a);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
