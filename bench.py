@@ -139,19 +139,6 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def current_sclk_mhz():
-    """The shader clock level sysfs marks as current ('*' in pp_dpm_sclk) of the first GPU, or None."""
-    import glob
-    for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
-        try:
-            for ln in open(f):
-                if ln.strip().endswith('*'):
-                    return int(''.join(ch for ch in ln.split(':', 1)[1] if ch.isdigit()))
-        except (OSError, ValueError, IndexError):
-            continue
-    return None
-
-
 def numa_nodes():
     """[(node id, [cpu ids])] from sysfs, nodes that have CPUs only."""
     import glob
@@ -399,24 +386,18 @@ def main():
                                                      _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
             timed(conv_once, 5)
             # the chip lowers its clock under sustained MFMA load (MI355X_MICROARCH.md "DVFS give-back"): a 3-launch burst from an
-            # idle chip runs at a higher clock than the 30 back-to-back launches the figure is quoted on -- both are reported,
-            # with the shader clock level sysfs marks on the idle chip and in the middle of 60 queued launches (best effort: None on boxes
-            # that hide it)
+            # idle chip beside the 30 back-to-back launches the figure is quoted on -- both are reported (they agree: the clock settles
+            # inside the first launch; the in-kernel clock itself is measured by tools/c1_stamps.py: 2.0-2.4 GHz, 2.14 on average --
+            # sysfs pp_dpm_sclk reads 95 MHz on these boxes and is not used)
             time.sleep(0.25)
             burst_us = timed(conv_once, 3) * 1e3
-            sclk_idle = current_sclk_mhz()
             conv_us = timed(conv_once, 30) * 1e3
-            for i in range(60):      # ~14 ms of queued launches: the clock level sysfs marks while they run
-                conv_once(i)
-            time.sleep(0.006)
-            sclk_load = current_sclk_mhz()
-            torch.cuda.synchronize(dev)
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
                 'kernel': 'C1 = og_conv3x3_tiled_' + a.dtype + ' (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '
                           '256->256 layer, residual + bias + ReLU epilogue fused',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK_TFLOPS, 'us_per_launch': round(conv_us, 1),
-                'us_per_launch_burst_of_3': round(burst_us, 1), 'sclk_mhz_idle_and_under_load': [sclk_idle, sclk_load],
+                'us_per_launch_burst_of_3': round(burst_us, 1), 
                 'achieved': round(conv_flop / (conv_us * 1e-6) / 1e12, 1),
                 'frac': round(conv_flop / (conv_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 'algorithmic_flop_per_launch': conv_flop}
@@ -475,13 +456,17 @@ def main():
     group = sharding.describe_group(dev)
     host_us = 1e6 * float(np.mean(pipe_host)) if pipe_host else None
     if rank == 0:
-        k1 = float(np.mean(stage_us['k1_generate_limbs']))
+        # OG_FUSED_UPSAMPLE=1 (PostProcess(fused_upsample=True) as the pipeline's decoder: the in-pipeline A/B of DESIGN.md section 4):
+        # the boundary is then K1f = og_upsample_nms_topk_f32 + og_collect_limbs_full_f32, which streams 16x fewer bytes -- the
+        # figure below stays priced on the hi-res algorithmic bytes and says which kernels ran
+        fused_k1 = 'k1_generate_limbs' not in stage_us and 'k1f_fused_limbs' in stage_us
+        k1 = float(np.mean(stage_us['k1f_fused_limbs' if fused_k1 else 'k1_generate_limbs']))
         k1_bytes = a.batch * K1_BYTES_PER_IMAGE * (a.size * a.size) / (640 * 640)
         achieved = k1_bytes / (k1 * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, profiles/README.md): only a figure
         # measured on THIS round's kernels is reported
         k1_kernels = ('band_topk_kernel', 'merge_collect_kernel')
-        traffic, traffic_file = k1_traffic(k1_kernels)
+        traffic, traffic_file = (None, None) if fused_k1 else k1_traffic(k1_kernels)
         imgs = a.batch * a.steps * world
         line = {
             'metric': METRIC,
@@ -497,7 +482,8 @@ def main():
             'per_rank_images_per_sec': per_rank,
             'poses_last_batch': [int(len(x)) for x in poses],
             'stage_us': {k: round(float(np.mean(v)), 2) for k, v in stage_us.items()},
-            'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
+            'roofline': {'kernel': 'K1f (fused_upsample): og_upsample_nms_topk_f32 + og_collect_limbs_full_f32, no hi-res tensor' if fused_k1 else
+                                   'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
                                    'merge_collect_kernel',
                          'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4),

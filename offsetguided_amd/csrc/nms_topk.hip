@@ -962,7 +962,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const long total = p.total;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
-    const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? env_int("OG_K1_HELPER", 1) : 0;   // extra wave: threshold exchange
+    const int helper = (hist != nullptr && p.nwaves < kMaxWaves) ? 1 : 0;   // extra wave: threshold exchange
     const dim3 block(64 * (p.nwaves + (helper & 1)));
     const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
     if (FUSED)

@@ -41,7 +41,7 @@ struct Row4 {
 
 __global__ void __launch_bounds__(64 * kCubicMaxWaves)
 bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, int w, int rows, int nbands,
-                int panel_cols, int total, int padded, int store_policy, const int32_t *__restrict__ kp_perm, int flip_planes, int C)
+                int panel_cols, int total, int padded, const int32_t *__restrict__ kp_perm, int flip_planes, int C)
 {
     const int wid = og_xcd_remap(blockIdx.x, padded);
     if (wid >= total) return;
@@ -62,7 +62,6 @@ bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, i
     }
     float *d = dst + (size_t)plane * (4 * h) * (4 * w);
     const int p0 = band * rows, p1 = min(p0 + rows, h);
-    const __amdgpu_buffer_rsrc_t plane_rsrc = __builtin_amdgcn_make_buffer_rsrc(d, 0, (int)((size_t)16 * h * w * sizeof(float)), 0x00020000);
 
     float wx[4][4];
 #pragma unroll
@@ -100,16 +99,7 @@ bicubic4_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float4 *dstp = reinterpret_cast<float4 *>(d + (size_t)(4 * p + r) * (4 * w) + 4 * q);
-                if (store_policy == 0) {
-                    *dstp = o[r];
-                } else {   // cache-policy bits of the store: 2 = nt, 16 = sc1 (write-through), 18 = both (knob OG_K1A_STORE)
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 v = __builtin_bit_cast(u32x4, o[r]);
-                    const int voff = (int)(((size_t)(4 * p + r) * (4 * w) + 4 * q) * sizeof(float));   // < 2^31: plane < 2^27 pixels
-                    if (store_policy == 2) __builtin_amdgcn_raw_buffer_store_b128(v, plane_rsrc, voff, 0, 2);
-                    else if (store_policy == 16) __builtin_amdgcn_raw_buffer_store_b128(v, plane_rsrc, voff, 0, 16);
-                    else __builtin_amdgcn_raw_buffer_store_b128(v, plane_rsrc, voff, 0, 18);
-                }
+                *dstp = o[r];      // plain store (nt / sc1 policies measured in round 2: no gain)
             }
         }
         a = b; b = c; c = e; e = f;
@@ -169,9 +159,8 @@ static int bicubic4_launch(const char *name, const float *src, long planes, int 
     const long total = planes * nbands;
     OG_REQUIRE(total < (1l << 30), OG_EINVAL, "%s: too many work items", name);
     const int padded = (int)((total + 7) / 8 * 8);
-    static const int store_policy = getenv("OG_K1A_STORE") ? atoi(getenv("OG_K1A_STORE")) : 0;
     hipLaunchKernelGGL(bicubic4_kernel, dim3(padded), dim3(64 * nwaves), 0, (hipStream_t)stream, src, dst, h, w, rows,
-                       nbands, panel_cols, (int)total, padded, store_policy, kp_perm, (int)planes, C);
+                       nbands, panel_cols, (int)total, padded, kp_perm, (int)planes, C);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

@@ -94,10 +94,6 @@ def main():
         lib.og_k1_wave_stamps.argtypes = [C.c_void_p]
         lib.og_k1_wave_stamps(wbuf.ctypes.data)
         report(buf, n * L, f'launch {it}:', wbuf, it + 1)
-        if os.environ.get('OG_K1_HELPER') == '9':   # debug statistics of the band kernel (helper bit 3), accumulated over the launches
-            off = 65536 + 256 + (n * c * 256 - 16) * 4
-            d = ws[off:off + 16].view(torch.int32).cpu().numpy()
-            print(f'   pushes so far {d[0]} over {d[2]} wave runs = {d[0] / max(d[2], 1):.1f} per wave; waves that ended above the start threshold {d[3]}')
         sys.stdout.flush()
 
 

@@ -4,7 +4,7 @@
 
   python tools/k1_bench.py [--libs a.so b.so ...] [--iters 40]
 
-For every library: (1) results of the single-launch form == three-launch form (bitwise), (2) HBM-cold timing (3 rotating
+For every library: (1) results of og_generate_limbs_f32 == the separate entry points (bitwise), (2) HBM-cold timing (3 rotating
 hi-res batches, 669 MB > Infinity Cache), (3) timing directly behind K1a (the hi-res batch has just been written: the
 decode pipeline's situation), (4) the three-launch form in both situations."""
 import argparse
@@ -60,7 +60,7 @@ def bench_inputs(dev, n_rot=3, batch=8, size=640):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bench-inputs', action='store_true', help='decoder inputs as in bench.py (network head outputs + synthetic maps) instead of the synthetic maps alone')
-    ap.add_argument('--forms', nargs='*', default=['single', 'two', 'in-band', 'three'], help='which forms of K1 to time (PMC passes: --forms two = the default form only)')
+    ap.add_argument('--forms', nargs='*', default=['two', 'three'], help='which forms of K1 to time (PMC passes: --forms two = the default form only)')
     ap.add_argument('--libs', nargs='*', default=[_lib.LIB_PATH])
     ap.add_argument('--iters', type=int, default=40)
     ap.add_argument('--batch', type=int, default=8)
@@ -99,15 +99,9 @@ def main():
             k1a(i)
         ws1 = torch.zeros(lib.og_generate_limbs_workspace_bytes(n, c, h, w, k), dtype=torch.uint8, device=dev)
         ws3 = torch.zeros(lib.og_topk_workspace_bytes(n * c, h, w, k), dtype=torch.uint8, device=dev)
-        limbs1 = torch.empty((n, L, k, 13), device=dev)
         limbs3 = torch.empty((n, L, k, 13), device=dev)
         sc = torch.empty((n, c, k), device=dev)
         ix = torch.empty((n, c, k), dtype=torch.int64, device=dev)
-
-        def single(i):
-            _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[i % a.rotate]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
-                                                 _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, None, None, _lib.ptr(limbs1),
-                                                 1, _lib.ptr(ws1), ws1.numel(), sp), lib)
 
         limbs2 = torch.empty((n, L, k, 13), device=dev)
         sc2 = torch.empty((n, c, k), device=dev)
@@ -118,11 +112,6 @@ def main():
                                                  _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
                                                  _lib.ptr(limbs2), 0, _lib.ptr(ws1), ws1.numel(), sp), lib)
 
-        def inband(i):   # flags 2: merge + pairing by last arrivers inside the band launch
-            _lib.check(lib.og_generate_limbs_f32(_lib.ptr(hrs[i % a.rotate]), _lib.ptr(t_off), 1, 2, None, 0, None, 0, n, c, h, w,
-                                                 _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
-                                                 _lib.ptr(limbs2), 2, _lib.ptr(ws1), ws1.numel(), sp), lib)
-
         def three(i):
             _lib.check(lib.og_nms_topk_f32(_lib.ptr(hrs[i % a.rotate]), n * c, h, w, k, _lib.ptr(sc), _lib.ptr(ix), _lib.ptr(ws3),
                                            ws3.numel(), sp), lib)
@@ -130,13 +119,9 @@ def main():
                                                      w, _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(limbs3), sp), lib)
 
         ok = True
-        for i in range(a.rotate if len(a.forms) == 4 else 0):
-            single(i)
+        for i in range(a.rotate if len(a.forms) == 2 else 0):
             three(i)
             two(i)
-            torch.cuda.synchronize()
-            ok = ok and torch.equal(limbs1, limbs3) and torch.equal(limbs2, limbs3) and torch.equal(sc2, sc) and torch.equal(ix2, ix)
-            inband(i)
             torch.cuda.synchronize()
             ok = ok and torch.equal(limbs2, limbs3) and torch.equal(sc2, sc) and torch.equal(ix2, ix)
         tick = int(ws1[:61440].view(torch.int32).abs().sum())
@@ -160,7 +145,7 @@ def main():
             t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
             return float(np.median(t)), float(t.min())
 
-        fns = {'single': single, 'two': two, 'in-band': inband, 'three': three}
+        fns = {'two': two, 'three': three}
         res = {f'{f} cold': timed(fns[f]) for f in a.forms}
         res.update({f'{f} after K1a': timed(fns[f], k1a) for f in a.forms})
         if a.burst:
@@ -179,12 +164,9 @@ def main():
                 for _ in range(reps):
                     ga @ gb
                 k1a(i)
-            res[f'single after {a.burst} ms of GEMM + K1a'] = timed(single, burst_then_k1a)
             res[f'two after {a.burst} ms of GEMM + K1a'] = timed(two, burst_then_k1a)
             res[f'three after {a.burst} ms of GEMM + K1a'] = timed(three, burst_then_k1a)
-        bal = ws1[61440:65536].view(torch.int32).cpu().numpy()
-        rows = np.diff(bal[16:16 + 257])
-        print(f'== {tag}: single == two == three: {ok}; tickets zero: {tick == 0}; rows per workgroup min/median/max', rows.min(), int(np.median(rows)), rows.max(), ' by XCD', np.round([rows[x::8].mean() for x in range(8)], 0))
+        print(f'== {tag}: two launches == three entry points: {ok}; state words zero: {tick == 0}')
         for name, (med, mn) in res.items():
             print(f'   {name:36s} median {med:7.1f} us  min {mn:7.1f} us   {nbytes / med / 1e6:5.2f} TB/s  frac {nbytes / med / 1e6 / 8:.3f}')
         sys.stdout.flush()

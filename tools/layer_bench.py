@@ -15,7 +15,7 @@ from offsetguided_amd import _lib  # noqa: E402
 LAYERS = [('s1', 8, 160, 256, 256, 13), ('s1', 8, 80, 256, 256, 12), ('s1', 8, 80, 256, 384, 0), ('s1', 8, 40, 384, 384, 14),
           ('s1', 8, 40, 384, 256, 2), ('s1', 8, 20, 384, 384, 20),
           ('s2', 8, 320, 128, 256, 1), ('s2', 8, 160, 256, 256, 2), ('s2', 8, 80, 256, 384, 2), ('s2', 8, 40, 384, 384, 2),
-          ('pw', 8, 160, 256, 256, 2), ('pw', 8, 160, 128, 256, 1)]
+          ('pw', 8, 160, 256, 256, 2), ('pw', 8, 160, 128, 256, 1), ('hd', 8, 160, 256, 64, 1)]
 
 
 def main():
@@ -29,13 +29,13 @@ def main():
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     cl = torch.channels_last
     for kind, n, hin, cin, cout, count in LAYERS:
-        taps = 1 if kind == 'pw' else 9
+        taps = 1 if kind in ('pw', 'hd') else 9
         hout = hin // 2 if kind == 's2' else hin
         xs = [torch.randn(n, cin, hin, hin, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
         outs = [torch.empty(n, cout, hout, hout, device=dev, dtype=dt).contiguous(memory_format=cl) for _ in range(3)]
         wt = (torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, device=dev) * (1.0 / (taps * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
         packed = torch.empty(wt.numel(), dtype=dt, device=dev)
-        order = {'s1': 0, 's2': 1, 'pw': 2}[kind]
+        order = {'s1': 0, 's2': 1, 'pw': 2, 'hd': 3}[kind]
         _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, order, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
         bias = torch.zeros(cout, device=dev)
         if kind == 's1':
@@ -57,6 +57,15 @@ def main():
             def once(i):
                 _lib.check(fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), None, _lib.ptr(outs[i % 3]), n, hin, hin, cin, cout, 1,
                               _lib.stream_ptr(dev)), lib)
+        elif kind == 'hd':     # the heads of the decoded stack: 17 + 38 channels as fp32 NCHW tensors
+            import ctypes as C
+            fn = _lib.lp(lib, 'og_conv1x1_heads', dt)
+            houts = [torch.empty((n, ch, hin, hin), dtype=torch.float32, device=dev) for ch in (17, 38)]
+            chans = (C.c_int * 2)(17, 38)
+            ptrs = (C.c_void_p * 2)(*[o.data_ptr() for o in houts])
+
+            def once(i):
+                _lib.check(fn(_lib.ptr(xs[i % 3]), cin, _lib.ptr(packed), _lib.ptr(bias), n, hin, hin, cout, 2, chans, ptrs, _lib.stream_ptr(dev)), lib)
         else:
             fn = _lib.lp(lib, 'og_conv1x1_tiled', dt)
 

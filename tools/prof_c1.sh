@@ -8,7 +8,7 @@ mkdir -p "$root/$out"
 cd /tmp && export TMPDIR=/tmp
 run() {   # tag, counters...
   tag=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$root/$out/$tag" -- python3 "$root/tools/conv_tiled_bench.py" --only 0 --rounds 2 --reps 4 $EXTRA > "$root/$out/$tag.log" 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$root/$out/$tag" -- python3 "$root/tools/c1_rounds.py" --shapes 8x160 --dtype bf16 --rounds 2 --reps 4 $EXTRA > "$root/$out/$tag.log" 2>&1
 }
 EXTRA="$*"
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES
