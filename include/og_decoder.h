@@ -338,6 +338,29 @@ int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias
  * (N,H,W,Cout) tensor in between is never written.  Shapes and workspace as og_conv3x3_tiled_bf16. */
 int og_conv3x3_tiled_up2_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *up, int N, int H,
                               int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
+/* Up to four DEPENDENT tiled 3x3 stride-1 layers (a residual's conv1 -> conv2, consecutive residuals: models/hourglass_104.py:50-79)
+ * as ONE launch: the workgroups of layer l + 1 follow those of layer l in the grid and wait, tile by tile, for the pixel tiles of
+ * layer l under their halo (one arrival counter per pixel tile) -- the partly filled last round of a layer's workgroups is filled
+ * by the next layer instead of idling to a kernel boundary.  Results are bit-identical to the layer-wise calls.
+ *   layers[l]: x (N,H,W,Cin) -> out (N,H,W,Cout) as og_conv3x3_tiled_bf16; layers[l].x is normally layers[l-1].out; skip may be any
+ *     tensor complete before the launch or the output of an EARLIER layer of the list; `up` (see og_conv3x3_tiled_up2_bf16) only on
+ *     the last layer (its `out` is then NULL).  All layers share N, H, W.
+ *   og_conv3x3_tiled_chain_supported: 1 = the list is served (every layer a 16x16 or 40x4 tile shape without K split, workgroup
+ *     counts multiples of 8, 2..4 layers).
+ *   workspace: og_conv3x3_tiled_chain_workspace_bytes(), 256-byte aligned, ZERO-INITIALISED once by the caller; every launch leaves
+ *     it zero (its last word is a sticky error word: a bounded wait ran out -- never observed).  Launches that share a workspace
+ *     must be stream-ordered. */
+typedef struct OgTiledLayerDesc {
+    const void *x, *w_packed;
+    const float *bias;
+    const void *skip;
+    void *out, *up;
+    int N, H, W, Cin, Cout, relu;
+} OgTiledLayerDesc;
+size_t og_conv3x3_tiled_chain_workspace_bytes(void);
+int og_conv3x3_tiled_chain_supported(const OgTiledLayerDesc *layers, int n_layers);
+int og_conv3x3_tiled_chain_bf16(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
+int og_conv3x3_tiled_chain_f16(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
 /* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
  * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
  * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.

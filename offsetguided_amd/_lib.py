@@ -76,6 +76,9 @@ SIGNATURES = {
     "og_conv3x3_tiled_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "og_conv3x3_tiled_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv3x3_tiled_up2_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "og_conv3x3_tiled_chain_workspace_bytes": (_sz, []),
+    "og_conv3x3_tiled_chain_supported": (_i, [_vp, _i]),
+    "og_conv3x3_tiled_chain_bf16": (_i, [_vp, _i, _vp, _sz, _vp]),
     "og_encode_heatmaps_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "og_encode_jitter_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "og_encode_offsets_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -109,6 +112,25 @@ def band_chain(descs, dtype, workspace, device):
     lib = load()
     arr = (BandLayerDesc * len(descs))(*descs)
     check(lp(lib, 'og_conv_band_chain', dtype)(arr, len(descs), ptr(workspace), workspace.numel(), stream_ptr(device)), lib)
+
+
+class TiledLayerDesc(C.Structure):
+    """OgTiledLayerDesc (include/og_decoder.h): one layer of an og_conv3x3_tiled_chain_* launch."""
+    _fields_ = [("x", _vp), ("w_packed", _vp), ("bias", _vp), ("skip", _vp), ("out", _vp), ("up", _vp),
+                ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("relu", _i)]
+
+
+def tiled_chain_supported(descs):
+    arr = (TiledLayerDesc * len(descs))(*descs)
+    return bool(load().og_conv3x3_tiled_chain_supported(arr, len(descs)))
+
+
+def tiled_chain(descs, dtype, workspace, device):
+    """og_conv3x3_tiled_chain_*: `descs` = list of TiledLayerDesc (2..4 dependent layers), `workspace` = a zero-initialised uint8
+    tensor of og_conv3x3_tiled_chain_workspace_bytes() (one per set of stream-ordered launches)."""
+    lib = load()
+    arr = (TiledLayerDesc * len(descs))(*descs)
+    check(lp(lib, 'og_conv3x3_tiled_chain', dtype)(arr, len(descs), ptr(workspace), workspace.numel(), stream_ptr(device)), lib)
 
 
 def lp(lib, stem, dtype):

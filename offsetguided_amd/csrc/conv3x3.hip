@@ -727,6 +727,21 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
 #ifndef OG_TILED_VAR16
 #define OG_TILED_VAR16 2
 #endif
+#ifdef OG_TILED_BIG
+    // experiment (tools/build_variants.sh conv3x3.hip big -DOG_TILED_BIG): ONE 8-wave workgroup per CU on a 32 x 16-pixel tile -- the
+    // same 64 pixels x 128 couts per wave, but eight waves share a weight stage (half the weight LDS-DMA per MFMA)
+    if (kind == 1 && W % 32 == 0 && h.ksplit == 1) {
+        constexpr int halo_ = ((32 + 2) * (16 + 2) * 5 * 16 + 1023) / 1024 * 1024;
+        constexpr int loop_ = 2 * halo_ + 3 * 128 * 64 + 1024, stage_ = 512 * (128 * 2 + 16);
+        const int lds_ = loop_ > stage_ ? loop_ : stage_;
+        static OgAttrOnce attr_;
+        if (attr_.need())
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<32, 16, 8, OG_TILED_VAR16, 8>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const long blocks_ = (long)N * (H / 16) * (W / 32) * h.n_tiles;
+        hipLaunchKernelGGL((conv3x3_tiled_kernel<32, 16, 8, OG_TILED_VAR16, 8>), dim3((unsigned)blocks_), dim3(512), lds_, st, h);
+    } else
+#endif
     if (kind == 1) TILED_LAUNCH(16, 16, 4, OG_TILED_VAR16);
     else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
     else TILED_LAUNCH(40, 4, 2, 2);
@@ -756,6 +771,87 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled_up2)(const void *x, const void *w_packed,
     OG_REQUIRE(up, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE((long)N * H * W * 4 * Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
     return conv3x3_tiled_impl(name, x, w_packed, bias, skip, nullptr, up, N, H, W, Cin, Cout, relu, workspace, workspace_bytes, stream);
+}
+
+// ---- chained launch of dependent tiled layers (conv3x3_tiled_chain_kernel) ----
+namespace {
+constexpr size_t kChainWsBytes = (size_t)(3 * kChainMaxTiles + 64) * sizeof(int);
+// 0 = not served; else the tile kind all layers share.  Fills the launch arguments when `c` is given.
+int tiled_chain_plan(const OgTiledLayerDesc *L, int n, TiledChainArgs *c)
+{
+    if (!L || n < 2 || n > 4) return 0;
+    int kind0 = 0;
+    long first = 0;
+    for (int l = 0; l < n; ++l) {
+        const OgTiledLayerDesc &d = L[l];
+        if (!d.x || !d.w_packed || !d.bias || d.N <= 0 || d.H <= 0 || d.W <= 0) return 0;
+        if (d.N != L[0].N || d.H != L[0].H || d.W != L[0].W) return 0;
+        if (l + 1 < n ? (d.up != nullptr || !d.out) : !(d.out || d.up)) return 0;
+        if (d.up && (uintptr_t)d.up % 16) return 0;
+        const long M = (long)d.N * d.H * d.W;
+        if (M * d.Cin >= (1l << 30) || M * d.Cout >= (1l << 30)) return 0;
+        const int kind = tiled_kind(d.H, d.W, d.Cin, d.Cout);
+        if ((kind != 1 && kind != 2) || (kind0 && kind != kind0)) return 0;
+        kind0 = kind;
+        const long items = tiled_items(kind, d.N, d.H, d.W, d.Cout);
+        if (items % 8 || items > (long)kMaxTiles || tiled_ksplit(kind, items, d.Cin) != 1) return 0;
+        if (items / (d.Cout / 128) > kChainMaxTiles) return 0;
+        if (c) {
+            ConvArgs &h = c->layer[l];
+            h = ConvArgs{};
+            h.x = (const unsigned short *)d.x; h.w = (const unsigned short *)d.w_packed; h.bias = d.bias;
+            h.skip = (const unsigned short *)d.skip; h.out = (unsigned short *)d.out; h.up = (unsigned short *)d.up;
+            h.N = d.N; h.H = d.H; h.W = d.W; h.Cin = d.Cin; h.Cout = d.Cout; h.M = (int)M; h.n_tiles = d.Cout / 128; h.relu = d.relu;
+            h.Hin = d.H; h.Win = d.W; h.stride = 1; h.taps = 9; h.ksplit = 1;
+            h.x_bytes = (int)(M * d.Cin * 2);
+            h.w_bytes = d.Cout * 9 * d.Cin * 2;
+            c->first[l] = (int)first;
+            c->counters_per_layer = (int)(items / (d.Cout / 128));
+        }
+        first += items;
+    }
+    if (first >= (1l << 30)) return 0;
+    if (c) {
+        for (int l = n; l <= 4; ++l) c->first[l] = (int)first;
+        c->n = n;
+    }
+    return kind0;
+}
+}  // namespace
+
+#ifndef OG_DT_F16
+OG_API size_t og_conv3x3_tiled_chain_workspace_bytes(void) { return kChainWsBytes; }
+OG_API int og_conv3x3_tiled_chain_supported(const OgTiledLayerDesc *layers, int n_layers) { return tiled_chain_plan(layers, n_layers, nullptr) ? 1 : 0; }
+#endif
+
+OG_API int OG_LP_NAME(og_conv3x3_tiled_chain)(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = OG_LP_STR("og_conv3x3_tiled_chain");
+    OG_REQUIRE(layers && workspace, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(workspace_bytes >= kChainWsBytes, OG_ENOSPC, "%s: workspace %zu < %zu bytes (og_conv3x3_tiled_chain_workspace_bytes)", name,
+               workspace_bytes, kChainWsBytes);
+    OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
+    TiledChainArgs c = {};
+    const int kind = tiled_chain_plan(layers, n_layers, &c);
+    OG_REQUIRE(kind != 0, OG_EUNSUPPORTED, "%s: the list is not served as one launch (og_conv3x3_tiled_chain_supported)", name);
+    // [3 x kChainMaxTiles arrival counters (a launch uses the first (n - 1) x its tiles of them) | exit count | error word | pad]
+    c.counters = (int *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+#define TILED_CHAIN_LAUNCH(TW_, TH_, WM_)                                                                              \
+    do {                                                                                                               \
+        constexpr int halo_ = ((TW_ + 2) * (TH_ + 2) * 5 * 16 + 1023) / 1024 * 1024;                                   \
+        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024;                                                              \
+        static OgAttrOnce attr_;                                                                                       \
+        if (attr_.need())                                                                                              \
+            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_chain_kernel<TW_, TH_, WM_, 2>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        hipLaunchKernelGGL((conv3x3_tiled_chain_kernel<TW_, TH_, WM_, 2>), dim3((unsigned)c.first[4]), dim3(256), lds_, st, c); \
+    } while (0)
+    if (kind == 1) TILED_CHAIN_LAUNCH(16, 16, 4);
+    else TILED_CHAIN_LAUNCH(40, 4, 2);
+#undef TILED_CHAIN_LAUNCH
+    OG_LAUNCH_CHECK(name);
+    return OG_OK;
 }
 
 OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out,

@@ -25,7 +25,8 @@ Environment switches (read at import; the measured-best value is the default): O
 3x3 stride 2 / 1x1 layers on the tiled kernels), OG_CONV_UP2 (1: merges on the producing convolution's epilogue),
 OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (1: capture order at the forks of
 depth >= 1), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024) /
-OG_CONV_BAND_CHAIN (0): the band-resident kernel for 10x10 / 5x5, OG_ENGINE_WHATIF (timing diagnosis,
+OG_CONV_BAND_CHAIN (0): the band-resident kernel for 10x10 / 5x5, OG_CONV_TILED_CHAIN (dependent 160x160 layers as one launch),
+OG_ENGINE_WHATIF (timing diagnosis,
 wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
 EXPERIMENTS.md and no longer exist as switches.
 """
@@ -92,6 +93,11 @@ CONV_TILED_MIN_PIXELS = 2048     # 20x20 at batch 8 = 3 200 pixels: 20 x 4 tiles
 # branches that run beside the bottom of the hourglass wait for it instead of sharing the chip).
 CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '1024'))
 CONV_BAND_CHAIN = int(os.environ.get('OG_CONV_BAND_CHAIN', '0'))
+# OG_CONV_TILED_CHAIN = W (0 = off): runs of up to four DEPENDENT 3x3 stride-1 layers of the tiled kernel (two residual blocks) whose
+# launches have at least W workgroups each go out as ONE chained launch (og_conv3x3_tiled_chain_*): the next layer's workgroups wait
+# tile by tile for the tiles under their halo and fill the partly filled last round of the layer before instead of idling to the
+# kernel boundary.  Pays where a layer has more workgroups than the chip has slots (512): the 160x160 layers at batch 8 (1 600).
+CONV_TILED_CHAIN = int(os.environ.get('OG_CONV_TILED_CHAIN', '0'))
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
@@ -450,6 +456,59 @@ def _chain_workspace(device):
     return buf
 
 
+def _tiled_chain_workspace(device):
+    key = ('tiled', device.index, _issuer.engine, _issuer.branch)
+    buf = _chain_ws.get(key)
+    if buf is None:
+        assert not torch.cuda.is_current_stream_capturing(), 'the chain workspace must exist before graph capture'
+        buf = _chain_ws[key] = torch.zeros(int(_lib.load().og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=device)
+    return buf
+
+
+def _tiled_chain_from(blocks, i, x, after_first=None):
+    """Residual blocks i, i + 1 (both convolutions of each on the tiled stride-1 kernel, no projection) as ONE chained launch of
+    two to four layers: -> (output, index of the first block not consumed) or None."""
+    if not (CONV_TILED_CHAIN and (CONV_TILED & 1) and x.is_cuda) or _WHATIF:
+        return None
+    cl = torch.channels_last
+    lib = _lib.load()
+    descs, cur, j = [], x, i
+    n, _, h, w = x.shape
+    while j < len(blocks) and len(descs) + 2 <= 4:
+        r = blocks[j]
+        if not (isinstance(r, _Residual) and r.skip is None and r.c1.hip3x3 and r.c2.hip3x3
+                and tuple(r.c1.stride) == (1, 1) and tuple(r.c2.stride) == (1, 1) and r.c1.w.dtype == cur.dtype):
+            break
+        c, mid, cout = cur.shape[1], r.c1.w.shape[0], r.c2.w.shape[0]
+        ok = True
+        for ci, co in ((c, mid), (mid, cout)):
+            kind = lib.og_conv3x3_tiled_supported(n, h, w, ci, co)
+            tile = {1: 256, 2: 160}.get(kind)
+            ok = ok and tile is not None and n * h * w // tile * (co // 128) >= CONV_TILED_CHAIN
+        if not ok or cout != c:
+            break
+        if not cur.is_contiguous(memory_format=cl):
+            cur = cur.contiguous(memory_format=cl)
+        y = torch.empty((n, mid, h, w), dtype=cur.dtype, device=cur.device, memory_format=cl)
+        out = torch.empty((n, cout, h, w), dtype=cur.dtype, device=cur.device, memory_format=cl)
+        for conv, cin_ in ((r.c1, c), (r.c2, mid)):
+            if conv.w_tiled is None:
+                assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
+                conv.w_tiled = torch.empty(conv.w.numel(), dtype=conv.w.dtype, device=conv.w.device)
+                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(conv.w), cin_, conv.w.shape[0], 0, _lib.ptr(conv.w_tiled), _lib.stream_ptr(cur.device)), lib)
+        descs.append((_lib.TiledLayerDesc(_lib.ptr(cur), _lib.ptr(r.c1.w_tiled), _lib.ptr(r.c1.b32), None, _lib.ptr(y), None,
+                                          n, h, w, c, mid, int(r.c1.relu)), (cur, y)))
+        descs.append((_lib.TiledLayerDesc(_lib.ptr(y), _lib.ptr(r.c2.w_tiled), _lib.ptr(r.c2.b32), _lib.ptr(cur), _lib.ptr(out), None,
+                                          n, h, w, mid, cout, int(r.c2.relu)), (y, out)))
+        cur, j = out, j + 1
+    if len(descs) < 2 or not _lib.tiled_chain_supported([d for d, _ in descs]):
+        return None
+    _lib.tiled_chain([d for d, _ in descs], cur.dtype, _tiled_chain_workspace(cur.device), cur.device)
+    if after_first is not None:
+        after_first()
+    return cur, j
+
+
 def _chain_from(blocks, i, x, after_first=None):
     """The longest run of convolutions starting at residual block i that og_conv_band_chain_* serves as ONE launch (stride-1 3x3
     layers on the band kernel's smallest tile, <= 16 layers): -> (output, index of the first block not consumed) or None.
@@ -514,7 +573,7 @@ def _run(seq, x, after_first=None):
     first kernel has been launched (fork point of a side branch, _Level)."""
     i = 0
     while i < len(seq):
-        run = _chain_from(seq, i, x, after_first if i == 0 else None)
+        run = _tiled_chain_from(seq, i, x, after_first if i == 0 else None) or _chain_from(seq, i, x, after_first if i == 0 else None)
         if run is None:
             x = seq[i](x, after_c1=after_first) if (i == 0 and after_first is not None) else seq[i](x)
             i += 1
@@ -699,9 +758,9 @@ class InferenceEngine:
             if s < self.stage:
                 if self.inters_[s].pointwise_ok(inter) and feat.shape == inter.shape and not _WHATIF:
                     # relu(inters_(inter) + cnvs_(feat)) as ONE 1x1 convolution over the concatenated channels
-                    inter = self.inters[s](self.inters_[s].pointwise(inter, x2=feat, other=self.cnvs_[s]))
+                    inter = _run([self.inters[s]], self.inters_[s].pointwise(inter, x2=feat, other=self.cnvs_[s]))
                 else:
-                    inter = self.inters[s](self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
+                    inter = _run([self.inters[s]], self.inters_[s](inter, skip=self.cnvs_[s].raw(feat)))
         if (self.heads_w is not None and (CONV_TILED & 4) and feat.shape[1] % 64 == 0 and len(self.head_channels) <= 4
                 and feat.is_contiguous(memory_format=torch.channels_last)):
             lib = _lib.load()

@@ -395,6 +395,91 @@ def test_conv3x3_tiled_up2_equals_conv_then_upsample_add(dev, shape, dtype):
         assert not torch.equal(want, up1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(8, 160, 160, 256, 4, False), (4, 64, 64, 128, 4, True), (12, 40, 40, 256, 3, True), (8, 40, 40, 384, 4, False), (8, 32, 32, 128, 2, False),
+                                  (4, 80, 80, 256, 4, True)])
+def test_conv3x3_tiled_chain_equals_layerwise_launches(dev, case, dtype):
+    """og_conv3x3_tiled_chain_* (dependent layers in one launch, workgroups of layer l + 1 waiting tile by tile for layer l) ==
+    the same layers as separate og_conv3x3_tiled_* / og_conv3x3_tiled_up2_* launches, bit for bit: residual structure (conv1 -> conv2 +
+    the block's input), 2 to 4 layers, both tile shapes, work-item chunks that cross images (halos handed over between XCDs), the
+    hourglass merge on the last layer; repeated launches, the workspace back to zero (its error word included) every time."""
+    n, h, w, c, layers, up_last = case
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(h * 131 + c + layers)
+    cl = torch.channels_last
+    x = torch.randn(n, c, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    up1 = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
+    packs, biases = [], []
+    for _ in range(layers):
+        wt = (torch.randn(c, c, 3, 3, generator=g) * (1.0 / (9 * c)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
+        packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
+        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), c, c, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+        packs.append(packed)
+        biases.append((torch.randn(c, generator=g) * 0.1).to(dev))
+    st = _lib.stream_ptr(dev)
+
+    def plan(outs, up):
+        """(input, skip, out, up) per layer: odd layers close a residual block (skip = the block's input)"""
+        res, cur, blk = [], x, x
+        for l in range(layers):
+            last = l == layers - 1
+            res.append((cur, blk if l % 2 == 1 else None, None if (last and up is not None) else outs[l], up if last else None))
+            cur = outs[l]
+            if l % 2 == 1:
+                blk = cur
+        return res
+
+    want_outs = [torch.empty_like(x) for _ in range(layers)]
+    want_up = up1.clone(memory_format=torch.preserve_format) if up_last else None
+    for l, (xi, skip, out, up) in enumerate(plan(want_outs, want_up)):
+        need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, c)
+        assert need == 0
+        fn = _lib.lp(lib, 'og_conv3x3_tiled_up2' if up is not None else 'og_conv3x3_tiled', dtype)
+        _lib.check(fn(_lib.ptr(xi), _lib.ptr(packs[l]), _lib.ptr(biases[l]), _lib.ptr(skip) if skip is not None else None,
+                      _lib.ptr(up if up is not None else out), n, h, w, c, c, 1, None, 0, st), lib)
+    ws = torch.zeros(int(lib.og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=dev)
+    for rep in range(3):
+        got_outs = [torch.full_like(x, float('nan')) for _ in range(layers)]
+        got_up = up1.clone(memory_format=torch.preserve_format) if up_last else None
+        descs = [_lib.TiledLayerDesc(_lib.ptr(xi), _lib.ptr(packs[l]), _lib.ptr(biases[l]), _lib.ptr(skip) if skip is not None else None,
+                                     _lib.ptr(out) if out is not None else None, _lib.ptr(up) if up is not None else None, n, h, w, c, c, 1)
+                 for l, (xi, skip, out, up) in enumerate(plan(got_outs, got_up))]
+        assert _lib.tiled_chain_supported(descs)
+        _lib.tiled_chain(descs, dtype, ws, dev)
+        torch.cuda.synchronize()
+        for l in range(layers - (1 if up_last else 0)):
+            assert torch.equal(got_outs[l], want_outs[l]), f'{case} launch {rep} layer {l}'
+        if up_last:
+            assert torch.equal(got_up, want_up), f'{case} launch {rep}: merged tensor'
+        assert int(ws.view(torch.int32).abs().sum().item()) == 0, 'the launch must leave its workspace zero (error word included)'
+
+
+def test_conv3x3_tiled_chain_api_errors(dev):
+    lib = _lib.load()
+    cl = torch.channels_last
+    x = torch.zeros(8, 128, 32, 32, device=dev, dtype=torch.float16).contiguous(memory_format=cl)
+    y = torch.zeros_like(x)
+    z = torch.zeros_like(x)
+    b = torch.zeros(128, device=dev)
+    ws = torch.zeros(int(lib.og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=dev)
+    d = lambda i, o, **kw: _lib.TiledLayerDesc(_lib.ptr(i), _lib.ptr(x), _lib.ptr(b), None, _lib.ptr(o) if o is not None else None,
+                                               kw.get('up'), 8, kw.get('h', 32), 32, 128, 128, 1)
+    ok = [d(x, y), d(y, z)]
+    assert _lib.tiled_chain_supported(ok)
+    assert not _lib.tiled_chain_supported(ok[:1])                                  # one layer is a plain launch
+    assert not _lib.tiled_chain_supported(ok * 3)                                  # more than four layers
+    assert not _lib.tiled_chain_supported([d(x, y), d(y, z, h=16)])                # layers must share N, H, W
+    assert not _lib.tiled_chain_supported([d(x, y, up=_lib.ptr(z)), d(y, z)])      # the merge only on the last layer
+    assert not _lib.tiled_chain_supported([d(x, None), d(y, z)])                   # an inner layer needs its output
+    arr = (_lib.TiledLayerDesc * 2)(*ok)
+    st = _lib.stream_ptr(dev)
+    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, _lib.ptr(ws), 128, st) == _lib.OG_ENOSPC
+    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, None, ws.numel(), st) == _lib.OG_EINVAL
+    assert lib.og_conv3x3_tiled_chain_f16(arr, 1, _lib.ptr(ws), ws.numel(), st) == _lib.OG_EUNSUPPORTED
+    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), st) == _lib.OG_OK
+    torch.cuda.synchronize()
+
+
 # (N, Hin, Win, Cin, Cout, stride, projection (H2, W2, Cin2, stride2) or None)
 BAND_SHAPES = [(8, 5, 5, 512, 512, 1, None), (8, 10, 10, 384, 384, 1, None), (2, 20, 20, 384, 384, 1, None),
                (8, 10, 10, 384, 512, 2, None), (2, 20, 20, 384, 384, 2, None), (8, 5, 5, 512, 512, 1, (10, 10, 384, 2)),
@@ -797,7 +882,7 @@ def test_engine_f16_matches_reference_golden(dev):
 
 @pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"},
                                    {"OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"}, {"OG_ENGINE_DEEP_SHARED": "2"},
-                                   {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}])
+                                   {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}, {"OG_CONV_TILED_CHAIN": "1"}])
 def test_engine_schedule_knobs(dev, knobs):
     """The engine's kept A/B switches (read at import): merges as their own launches instead of on the producing convolution's
     epilogue, up1 branch captured before the trunk below the fork, the small levels back on the split-K kernel with every up1
