@@ -727,21 +727,6 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
 #ifndef OG_TILED_VAR16
 #define OG_TILED_VAR16 2
 #endif
-#ifdef OG_TILED_BIG
-    // experiment (tools/build_variants.sh conv3x3.hip big -DOG_TILED_BIG): ONE 8-wave workgroup per CU on a 32 x 16-pixel tile -- the
-    // same 64 pixels x 128 couts per wave, but eight waves share a weight stage (half the weight LDS-DMA per MFMA)
-    if (kind == 1 && W % 32 == 0 && h.ksplit == 1) {
-        constexpr int halo_ = ((32 + 2) * (16 + 2) * 5 * 16 + 1023) / 1024 * 1024;
-        constexpr int loop_ = 2 * halo_ + 3 * 128 * 64 + 1024, stage_ = 512 * (128 * 2 + 16);
-        const int lds_ = loop_ > stage_ ? loop_ : stage_;
-        static OgAttrOnce attr_;
-        if (attr_.need())
-            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<32, 16, 8, OG_TILED_VAR16, 8>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const long blocks_ = (long)N * (H / 16) * (W / 32) * h.n_tiles;
-        hipLaunchKernelGGL((conv3x3_tiled_kernel<32, 16, 8, OG_TILED_VAR16, 8>), dim3((unsigned)blocks_), dim3(512), lds_, st, h);
-    } else
-#endif
     if (kind == 1) TILED_LAUNCH(16, 16, 4, OG_TILED_VAR16);
     else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
     else TILED_LAUNCH(40, 4, 2, 2);
