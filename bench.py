@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--no-extras', action='store_true',
                     help='headline region only: skip the decoder-only / backbone-only / conv / HBM-cold / flip measurements')
     ap.add_argument('--allow-diagnostic', action='store_true',
-                    help='run although a switch that produces WRONG RESULTS or loads a foreign library is set (OG_ENGINE_WHATIF, '
+                    help='run although a switch that produces WRONG RESULTS or loads a foreign library is set (OG_ENGINE_WHATIF, OG_BENCH_ZERO_WEIGHTS, '
                          'OG_DECODER_LIB): the JSON line then carries "diagnostic": true and is not a measurement')
     ap.add_argument('--no-alt-dtype', '--no-f16', dest='no_alt_dtype', action='store_true',
                     help='skip the figure for the other 16-bit arithmetic (bf16 beside the fp16 headline, or fp16 beside --dtype bf16)')
@@ -100,7 +100,7 @@ def bench_init(model, seed):
                 m.weight.data.mul_(1e-4)
 
 
-DIAGNOSTIC_SWITCHES = ('OG_ENGINE_WHATIF', 'OG_DECODER_LIB')   # wrong-results / foreign-library switches of the product path
+DIAGNOSTIC_SWITCHES = ('OG_ENGINE_WHATIF', 'OG_DECODER_LIB', 'OG_BENCH_ZERO_WEIGHTS')   # wrong-results / foreign-library switches of the product path
 
 
 def knobs():
@@ -255,6 +255,11 @@ def main():
     margs.batch_size = a.batch
     model, _ = models.model_factory(margs)
     bench_init(model, 1234)
+    if os.environ.get('OG_BENCH_ZERO_WEIGHTS') == '1':
+        # timing diagnosis (refused without --allow-diagnostic): all-zero weights -> every MFMA of the forward runs on zeros, the same
+        # instruction stream at the lowest switching energy: what the step would take if the chip held its clock
+        for prm in model.parameters():
+            prm.data.zero_()
     n_rot = 3
 
     class Pipeline:
