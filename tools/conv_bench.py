@@ -98,11 +98,7 @@ def main():
         t_ref = graph_time(miopen, a.reps, cold=not a.warm)
         gflop = 2 * n * h * w * cout * 9 * cin / 1e9
         line = f'{n}x{h}x{w} {cin}->{cout} ({gflop:.2f} GF): miopen+epilogue {t_ref:7.1f} us'
-        for plan in [''] + [p for p in a.plans.split(',') if p]:
-            if plan:
-                os.environ['OG_CONV_PLAN'] = plan.replace(':', ',')
-            else:
-                os.environ.pop('OG_CONV_PLAN', None)
+        for plan in ['']:      # (the OG_CONV_PLAN arms of rounds 1-3 left the library: the plan is the library's own)
             out.zero_()
             try:
                 ours()
@@ -190,11 +186,7 @@ def main_conv2d(a):
         t_ref = graph_time(miopen, reps)
         gflop = 2 * n * ho * wo * cout * k * k * cin / 1e9
         line = f'[{si}] {n}x{h}x{w} {cin}->{cout} k{k} s{st} ({gflop:.2f} GF): miopen {t_raw:7.1f} +epilogue {t_ref:7.1f} us'
-        for plan in [''] + [p for p in a.plans.split(',') if p]:
-            if plan:
-                os.environ['OG_CONV_PLAN'] = plan.replace(':', ',')
-            else:
-                os.environ.pop('OG_CONV_PLAN', None)
+        for plan in ['']:      # (the OG_CONV_PLAN arms of rounds 1-3 left the library: the plan is the library's own)
             out.zero_()
             try:
                 ours()

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of the two large-level 3x3 kernels in ONE process, interleaved rounds (cdna_hip_programming.md rule 24):
-og_conv3x3_bf16 (first-generation halo kernel: one 8-wave workgroup per CU) against og_conv3x3_tiled_bf16 (two 4-wave
-workgroups per CU, pre-tiled weights).  Random operands, rotating activations, `reps` back-to-back launches per HIP graph;
-prints the median and the minimum us per launch over the rounds and the TFLOP/s of the median, plus the largest difference
-between the two kernels' outputs (same operands, different fp32 summation order)."""
+"""og_conv3x3_tiled_* (two 4-wave workgroups per CU, pre-tiled weights) against MIOpen's convolution + og_bias_act_* on the
+large-level 3x3 shapes, in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): random operands, rotating
+activations, `reps` back-to-back launches per HIP graph; median / minimum us per launch, TFLOP/s of the median, and the largest
+difference between the two results.  --s2: the stride-2 kernel on the down-sampling layers.  (The round-2 halo kernel and the
+OG_TILED_VAR / OG_TILED_KSPLIT arms this tool used to time left the library in round 4: profiles/r03_*.)"""
 import argparse
 import os
 import sys
@@ -18,61 +18,50 @@ SHAPES = [(8, 160, 160, 256, 256), (8, 80, 80, 256, 256), (8, 40, 40, 384, 384),
 
 
 def main():
+    import torch.nn.functional as F
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=8)
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--dtype', choices=['bf16', 'f16'], default='bf16')
-    ap.add_argument('--vars', type=int, nargs='*', default=[0], help='OG_TILED_VAR values to compare (tuning switches of the tiled kernel)')
-    ap.add_argument('--no-halo', action='store_true', help='skip the first-generation kernel')
-    ap.add_argument('--ksplits', type=int, nargs='*', default=[], help='OG_TILED_KSPLIT values to compare (0 = the plan\'s own choice)')
+    ap.add_argument('--no-miopen', action='store_true', help='time the tiled kernel only')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     cl = torch.channels_last
+    torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)
     for si, (n, h, w, cin, cout) in enumerate(SHAPES):
         if a.only and si not in a.only:
             continue
         xs = [torch.randn(n, cin, h, w, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
         skip = torch.randn(n, cout, h, w, device=dev).to(dt).contiguous(memory_format=cl)
-        outs = [torch.empty_like(skip) for _ in range(2)]
+        out = torch.empty_like(skip)
         wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
         bias = torch.randn(cout, device=dev) * 0.1
         packed = torch.empty(wt.numel(), dtype=dt, device=dev)
         _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
-        ws = torch.zeros(max(lib.og_conv3x3_workspace_bytes(n * h * w, cin, cout), 256), dtype=torch.uint8, device=dev)
-        old_fn, new_fn = _lib.lp(lib, 'og_conv3x3', dt), _lib.lp(lib, 'og_conv3x3_tiled', dt)
+        tws = torch.zeros(max(int(lib.og_conv3x3_tiled_workspace_bytes(n, h, w, cin, cout)), 256), dtype=torch.uint8, device=dev)
+        new_fn, ba_fn = _lib.lp(lib, 'og_conv3x3_tiled', dt), _lib.lp(lib, 'og_bias_act', dt)
+        holder = {}
 
-        def old(i, o=0):
-            _lib.check(old_fn(_lib.ptr(xs[i % 3]), _lib.ptr(wt), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w, cin,
-                              cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
+        def miopen(i):
+            y = F.conv2d(xs[i % 3], wt, None, 1, 1)
+            _lib.check(ba_fn(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(skip), n * h * w, cout, 1, _lib.stream_ptr(dev)), lib)
+            holder['y'] = y
 
-        # K-split workspace for ANY split the arms may force (allocated once: the captured graphs keep its address)
-        tws = torch.zeros(256 + 65536 + n * h * w * cout * 4 * 8, dtype=torch.uint8, device=dev)
-
-        def new(i, o=1):
-            _lib.check(new_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(outs[o]), n, h, w,
+        def new(i):
+            _lib.check(new_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(out), n, h, w,
                               cin, cout, 1, _lib.ptr(tws), tws.numel(), _lib.stream_ptr(dev)), lib)
 
-        if not a.no_halo:
-            old(0)
-        new(0)
+        arms = [('tiled', new)] + ([] if a.no_miopen else [('miopen+epilogue', miopen)])
+        for _, fn in arms:
+            fn(0)
         torch.cuda.synchronize()
-        diff = (outs[0].float() - outs[1].float()).abs().max().item()
+        diff = (holder['y'].float() - out.float()).abs().max().item() if not a.no_miopen else float('nan')
         graphs = {}
-        arms = ([] if a.no_halo else [('halo', old, None)]) + [('tiled' + (f'/v{v}' if v else ''), new, v) for v in a.vars]
-        arms += [(f'tiled/ks{ks}', new, -ks - 1) for ks in a.ksplits]
-        for name, fn, var in arms:
-            os.environ.pop('OG_TILED_KSPLIT', None)
-            if var is not None and var < 0:
-                if var != -1:
-                    os.environ['OG_TILED_KSPLIT'] = str(-var - 1)
-                var = 0
-            if var is not None:
-                os.environ['OG_TILED_VAR'] = str(var)      # read by the library at every call: fixed at graph capture
-                os.environ['OG_TILED_VAR40'] = str(var)
+        for name, fn in arms:
             for i in range(a.reps):
                 fn(i)
             torch.cuda.synchronize()
@@ -96,7 +85,7 @@ def main():
             t = sorted(t)
             med = t[len(t) // 2]
             line += f'  {name} {med:7.1f} us (min {t[0]:7.1f}) = {flop / med / 1e6:6.0f} TFLOP/s'
-        print(line + f'  | max |halo - tiled| = {diff:.4f}', flush=True)
+        print(line + f'  | max |miopen - tiled| = {diff:.4f}', flush=True)
 
 
 def main_s2():
@@ -107,7 +96,6 @@ def main_s2():
     ap.add_argument('--s2', action='store_true')
     ap.add_argument('--reps', type=int, default=8)
     ap.add_argument('--rounds', type=int, default=7)
-    ap.add_argument('--vars', type=int, nargs='*', default=[0])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()
@@ -137,9 +125,7 @@ def main_s2():
         torch.cuda.synchronize()
         diff = (holder['y'].float() - out.float()).abs().max().item()
         graphs = {}
-        for name, fn, var in [('miopen+epilogue', miopen, None)] + [('tiled_s2' + (f'/v{v}' if v else ''), ours, v) for v in a.vars]:
-            if var is not None:
-                os.environ['OG_TILED_S2_VAR'] = str(var)
+        for name, fn in [('miopen+epilogue', miopen), ('tiled_s2', ours)]:
             for i in range(a.reps):
                 fn(i)
             torch.cuda.synchronize()
