@@ -59,7 +59,6 @@ def graph_time(fn, reps, rounds=5, cold=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
-    ap.add_argument('--plans', default='', help='comma list of "bm:ksplit" overrides to sweep, e.g. 64:4,64:8,128:2')
     ap.add_argument('--only', type=int, nargs='*', default=[])
     ap.add_argument('--stamps', action='store_true', help='print in-kernel timeline (us) of one cold launch per plan')
     ap.add_argument('--warm', action='store_true', help='no cache flush between timed replays (weights stay in the Infinity Cache)')
