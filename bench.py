@@ -542,7 +542,7 @@ def harness_block(a, model, dev, n_batches=24):
 
     def loader():
         for b in range(n_batches + 2):
-            if b == 2:
+            if b == 3:      # run_images reads ONE batch ahead: batch 3 is requested right before batch 2 is processed
                 torch.cuda.synchronize(dev)
                 marks['t0'] = time.perf_counter()
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]

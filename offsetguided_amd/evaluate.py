@@ -133,16 +133,43 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
         for image_poses, image_meta in zip(poses.result(), metas):   # zip drops the padded images of a ragged batch
             poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids)
 
-    preprocess = None
-    for batch_idx, (images, _, metas) in enumerate(data_loader):
-        if isinstance(images, (list, tuple)):
+    preprocess, packer = [None], [None]
+
+    def ahead(loader):
+        """The loader one batch ahead; a batch of raw images is packed into pinned memory on a worker thread meanwhile (host
+        memcpys: the reference does this part in DataLoader workers, evaluate.py:170-178)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        def prepare(batch):
+            images = batch[0]
+            if not isinstance(images, (list, tuple)):
+                return batch, None
+            if preprocess[0] is None:
+                from .transforms import EvalPreprocess
+                preprocess[0] = EvalPreprocess(args.long_edge, device=dev, fixed_height=args.fixed_height)
+                packer[0] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='og-pack')
+            imgs = list(images)
+            return (imgs,) + tuple(batch[1:]), packer[0].submit(preprocess[0].pack, imgs)
+
+        it = iter(loader)
+        try:
+            nxt = prepare(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = prepare(next(it))
+            except StopIteration:
+                nxt = None
+            yield cur
+
+    for batch_idx, ((images, _, metas), packed) in enumerate(ahead(data_loader)):
+        if packed is not None:
             # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
             # (RescaleLongAbsolute + CenterPad, or with --fixed-height RescaleHighAbsolute + RightDownPad of :150-156, then
-            # ToTensor + Normalize; pinned double-buffered H2D); metas are derived here
-            if preprocess is None:
-                from .transforms import EvalPreprocess
-                preprocess = EvalPreprocess(args.long_edge, device=dev, fixed_height=args.fixed_height)
-            images, metas = preprocess(list(images), image_ids=[m['image_id'] for m in metas])
+            # ToTensor + Normalize; pinned staging packed a batch ahead, one H2D copy); metas are derived here
+            images, metas = preprocess[0](images, image_ids=[m['image_id'] for m in metas], packed=packed.result())
         images = feeder(images)
         full_batch = full_batch or images.shape[0]
         if images.shape[0] < full_batch:   # last batch of the dataset: fill up to the engine's batch, results are dropped
@@ -170,6 +197,8 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                 args.batch_size / (batch_time.avg or per_batch)))
     if pending is not None:
         collect(pending)
+    if packer[0] is not None:
+        packer[0].shutdown()
     return result_keypoints, result_image_ids
 
 

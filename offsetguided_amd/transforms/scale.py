@@ -67,8 +67,10 @@ def resize_cubic(image, new_h, new_w, device='cuda:0'):
 
 class EvalPreprocess:
     """images: list of (h, w, 3) uint8 RGB arrays of any size -> ((N, 3, T, T) fp32 on the device, metas) with the metas
-    `annotations_inverse` needs (offset, scale) after rescale + centre pad.  Host images are staged through two pinned
-    buffers and copied asynchronously; batch i+1 can be prepared while batch i is in the network."""
+    `annotations_inverse` needs (offset, scale) after rescale + centre pad.  Host images are packed into one of three pinned
+    buffers and copied asynchronously; batch i+1 can be prepared while batch i is in the network, and its packing -- pure host
+    work, a memcpy per image -- may run on another thread (`pack`, used by evaluate.run_images: the reference prepares its
+    batches in DataLoader workers, evaluate.py:170-178)."""
 
     def __init__(self, long_edge, device='cuda:0', mean=data_mean, std=data_std, fill=FILL, fixed_height=False, max_stride=128):
         """fixed_height: RescaleHighAbsolute(long_edge) + RightDownPad(max_stride) (evaluate.py:150-156) instead of
@@ -76,7 +78,7 @@ class EvalPreprocess:
         self.long_edge, self.device, self.fixed_height, self.max_stride = long_edge, torch.device(device), fixed_height, max_stride
         f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
         self._mean, self._std, self._fill = f3(mean), f3(std), f3(fill)
-        self._stage, self._turn = [None, None], 0
+        self._stage, self._turn = [None, None, None], 0
         self.copy_stream = torch.cuda.Stream(self.device)
 
     def _staging(self, nbytes):
@@ -85,12 +87,12 @@ class EvalPreprocess:
             buf = self._stage[self._turn] = [torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8).pin_memory(), None]
         if buf[1] is not None:
             buf[1].synchronize()          # the copies that last used this staging buffer have left the host
-        self._turn ^= 1
+        self._turn = (self._turn + 1) % len(self._stage)
         return buf
 
-    def __call__(self, images, image_ids=None):
-        lib = _lib.load()
-        T = self.long_edge
+    def pack(self, images):
+        """Host part of a batch: the images copied into one pinned staging buffer.  No device call except the wait for the buffer's
+        previous H2D copy; may run on a worker thread while the caller's thread feeds the device (one pack at a time)."""
         sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
         total = sum(h * w * 3 for h, w in sizes)
         stage = self._staging(total)
@@ -100,6 +102,14 @@ class EvalPreprocess:
             assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'images are (h, w, 3) uint8 RGB'
             np.copyto(stage_np[o:o + h * w * 3].reshape(h, w, 3), im)
             o += h * w * 3
+        return stage, sizes, total
+
+    def __call__(self, images, image_ids=None, packed=None):
+        """packed: the result of pack(images) (same images), or None to pack here."""
+        lib = _lib.load()
+        T = self.long_edge
+        stage, sizes, total = packed if packed is not None else self.pack(images)
+        assert len(sizes) == len(images)
         with torch.cuda.stream(self.copy_stream):
             # allocated on the copy stream's pool: a block of the compute stream's pool may still be in use by kernels
             # queued there (the host runs a batch ahead), and the copy stream does not wait for them
