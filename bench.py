@@ -528,10 +528,11 @@ def main():
         dist.destroy_process_group()
 
 
-def harness_block(a, model, dev, n_batches=24):
+def harness_block(a, model, dev, n_batches=24, warm=6):
     """img/s of offsetguided_amd.evaluate.run_images (reference evaluate.py:125-300) from raw host images to COCO result dicts:
-    batches of (h, w, 3) uint8 RGB arrays of eight COCO-like sizes in pageable memory; the first two batches build the engine
-    (untimed), the next `n_batches` are timed with the host clock (device synchronised on both sides)."""
+    batches of (h, w, 3) uint8 RGB arrays of eight COCO-like sizes in pageable memory; the first `warm` batches build the engine and
+    allocate the pinned staging / landing buffers (a hipHostMalloc costs 50-60 ms: one inside the timed region reads as 8.4 instead of
+    6.3 ms per batch), the next `n_batches` are timed with the host clock (device synchronised on both sides)."""
     from offsetguided_amd import evaluate
     rng = np.random.default_rng(0)
     sizes = [(480, 640), (427, 640), (640, 480), (375, 500), (500, 375), (640, 640), (333, 500), (612, 612)]
@@ -541,8 +542,8 @@ def harness_block(a, model, dev, n_batches=24):
     marks = {}
 
     def loader():
-        for b in range(n_batches + 2):
-            if b == 3:      # run_images reads ONE batch ahead: batch 3 is requested right before batch 2 is processed
+        for b in range(n_batches + warm):
+            if b == warm + 1:      # run_images reads ONE batch ahead: batch warm + 1 is requested right before batch `warm` is processed
                 torch.cuda.synchronize(dev)
                 marks['t0'] = time.perf_counter()
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
@@ -550,7 +551,7 @@ def harness_block(a, model, dev, n_batches=24):
     results, ids = evaluate.run_images(args, loader(), model=model)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - marks['t0']
-    assert len(ids) == (n_batches + 2) * a.batch
+    assert len(ids) == (n_batches + warm) * a.batch
     return {'value': round(n_batches * a.batch / dt, 2), 'unit': 'images/sec', 'batches': n_batches,
             'ms_per_batch': round(dt / n_batches * 1e3, 3),
             'input': f'{a.batch} raw (h, w, 3) uint8 RGB host images per batch, eight COCO-like sizes (333x500 ... 640x640), pageable memory',
