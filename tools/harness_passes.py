@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Why the harness figure is bimodal on the shared boxes (diagnosis): evaluate.run_images timed repeatedly in one process, with the host
-time of the pinned packing, of the whole preprocessing call and of the engine call accumulated per pass."""
+"""bench.py's harness block (evaluate.run_images from raw host images) eight times in one process: img/s per pass, host time per stage
+(packing on the worker thread, preprocessing call, engine call, decoder submit, waiting for the previous batch's poses) and the device-side
+pitch between consecutive engine launches.  (Found that the 'bimodal' harness figures of round 4 were a pinned allocation inside the timed
+region.)"""
 import os
 import sys
 import time
