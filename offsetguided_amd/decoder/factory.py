@@ -169,7 +169,10 @@ class PostProcess(torch.nn.Module):
             poses, meta = self.limb_group.group_device(limbs)
             # a pinned slot nobody is waiting on (the pool grows with the number of outstanding handles: a third submit()
             # before the first result() gets a third slot instead of overwriting the first batch's landing area)
-            pool = self._pinned.setdefault((tuple(poses.shape), tuple(meta.shape)), [])
+            pool = self._pinned.get((tuple(poses.shape), tuple(meta.shape)))
+            if pool is None:    # three slots at once, at the first batch of a shape: a pinned allocation costs 50-60 ms of host time,
+                                # and a pipelined caller (run_images: one batch ahead) needs the third one a few batches in
+                pool = self._pinned[(tuple(poses.shape), tuple(meta.shape))] = [_HostSlot(poses.shape, meta.shape) for _ in range(3)]
             for sl in pool:     # slots of handles that were dropped unread: free once their copy has landed
                 if sl.orphan is not None and sl.orphan.query():
                     sl.busy, sl.orphan = False, None
