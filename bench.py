@@ -111,7 +111,7 @@ def knobs():
 
 
 def diagnostic_switches():
-    return [k for k in DIAGNOSTIC_SWITCHES if os.environ.get(k, '')]
+    return [k for k in DIAGNOSTIC_SWITCHES if os.environ.get(k, '') and not (k == 'OG_BENCH_ZERO_WEIGHTS' and os.environ[k] == '0')]
 
 
 def k1_traffic(kernels):
