@@ -157,22 +157,75 @@ def numa_nodes():
     return out
 
 
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
+def gpu_numa_nodes(sysfs='/sys', env=None):
+    """NUMA node of every VISIBLE HIP device, in HIP device order, WITHOUT a HIP call (pinning happens before the process
+    touches the GPU): the KFD topology lists the GPUs in the order the runtime enumerates them (nodes with simd_count > 0,
+    by node id; nodes whose properties are unreadable belong to other containers and are skipped, as the runtime skips them --
+    seen on this pool: an 8-GPU host, one readable GPU node, renderD128..156 on node 0, renderD160..184 on node 1); a node's
+    drm_render_minor names its DRM device, whose PCI function carries numa_node.
+    ROCR_VISIBLE_DEVICES, then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES select and reorder (index lists only; UUID lists
+    leave the answer unknown).  -> list of ints (-1 = sysfs does not say), or None when the topology cannot be read."""
+    import glob
+    env = os.environ if env is None else env
+    gpus = []
+    paths = glob.glob(os.path.join(sysfs, 'class/kfd/kfd/topology/nodes/[0-9]*'))
+    for d in sorted(paths, key=lambda q: int(os.path.basename(q))):
+        props = _read(os.path.join(d, 'properties'))
+        if props is None:
+            continue      # a GPU this process may not open (device cgroup of a container): the runtime does not enumerate it either
+        kv = dict(line.split(None, 1) for line in props.splitlines() if len(line.split(None, 1)) == 2)
+        if int(kv.get('simd_count', '0')) <= 0:
+            continue                                         # a CPU node
+        minor = int(kv.get('drm_render_minor', '-1'))
+        node = _read(os.path.join(sysfs, f'class/drm/renderD{minor}/device/numa_node')) if minor >= 0 else None
+        gpus.append(int(node) if node not in (None, '') else -1)
+    if not gpus:
+        return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        spec = env.get(var)
+        if var == 'CUDA_VISIBLE_DEVICES' and env.get('HIP_VISIBLE_DEVICES') is not None:
+            continue                                         # HIP reads one of the two
+        if spec is None or spec.strip() == '':
+            continue
+        try:
+            idx = [int(t) for t in spec.split(',')]
+        except ValueError:
+            return None                                      # UUIDs: not resolvable from here
+        gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+    return gpus
+
+
 def pin_rank(local_rank, world):
     """One process per GPU, eight of them on one host with a 6 ms step: keep a rank's threads (launch thread, pinned-copy
-    helpers, the CPU baseline's workers stay out of this) on the NUMA node of its GPU.  The GPUs of an 8-GPU MI355X node hang
-    off the host's NUMA nodes in device order (GPU 0-3 socket 0, 4-7 socket 1; with NPS4: two per node), so rank r gets node
-    r * nodes // world.  Runs BEFORE the process makes any HIP call; OG_BENCH_NUMA=0 switches it off.  -> description or None."""
+    helpers; the CPU baseline's workers stay out of this) on the NUMA node of ITS GPU, read from sysfs (gpu_numa_nodes: KFD
+    topology -> DRM device -> PCI numa_node).  Only when sysfs has no answer (-1, containers without the topology) the rule of
+    thumb applies: the GPUs of an 8-GPU MI355X node hang off the host's NUMA nodes in device order, rank r -> node
+    r * nodes // world; `source` in the result says which.  Runs BEFORE the process makes any HIP call; OG_BENCH_NUMA=0
+    switches it off.  -> description or None."""
     if os.environ.get('OG_BENCH_NUMA', '1') == '0' or world <= 1 or not hasattr(os, 'sched_setaffinity'):
         return None
     nodes = numa_nodes()
     if len(nodes) < 2:
         return None
-    node, cpus = nodes[min(local_rank * len(nodes) // world, len(nodes) - 1)]
+    by_id = dict(nodes)
+    of_gpu = gpu_numa_nodes()
+    if of_gpu is not None and local_rank < len(of_gpu) and of_gpu[local_rank] in by_id:
+        node, cpus, source = of_gpu[local_rank], by_id[of_gpu[local_rank]], 'sysfs'
+    else:
+        node, cpus = nodes[min(local_rank * len(nodes) // world, len(nodes) - 1)]
+        source = 'device-order rule'
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
     if not allowed:
         return None
     os.sched_setaffinity(0, allowed)
-    return {'node': node, 'cpus': len(allowed)}
+    return {'node': node, 'cpus': len(allowed), 'source': source}
 
 
 def launch_ranks(a):
@@ -433,7 +486,7 @@ def main():
                      'k1a_upsample_us': round(float(np.mean(f_stage['k1a_upsample'])), 2),
                      'k1_generate_limbs_us': round(float(np.mean(f_stage['k1_generate_limbs'])), 2),
                      'workload': f'bs{a.batch} {a.size}x{a.size} + flip-test: {2 * a.batch} images through the backbone per step, '
-                                 'K0 flip merge, full decoder (BASELINE configs[2])'}
+                                 ('K0 flip merge as its own pass' if 'k0_flip_merge' in f_stage else 'flip merge folded into the loads of K1a / K1 (no K0 pass)') + ', full decoder (BASELINE configs[2])'}
         del fpipe
 
     # ---- the other 16-bit arithmetic timed in the same process, same steps (headline fp16 = the reference's apex-O2 arithmetic,
@@ -456,10 +509,14 @@ def main():
     harness = None
     if not a.no_extras and not a.no_harness and not a.flip and a.inflight == 1 and rank == 0:
         torch.cuda.empty_cache()
-        # the figure depends on what else runs on the (shared) host: two passes, the better one reported, both listed
-        runs = [harness_block(a, model, dev) for _ in range(2)]
-        harness = max(runs, key=lambda h: h['value'])
+        # the figure depends on what else runs on the (shared) host: three passes, the MEDIAN is `value`, all listed, the best one
+        # kept as `best` (never quoted as "the" harness rate)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # run_images prints its progress lines: stdout carries the ONE JSON line
+            runs = [harness_block(a, model, dev) for _ in range(3)]
+        harness = sorted(runs, key=lambda h: h['value'])[1]
         harness['runs'] = [h['value'] for h in runs]
+        harness['best'] = max(harness['runs'])
 
     group = sharding.describe_group(dev)
     host_us = 1e6 * float(np.mean(pipe_host)) if pipe_host else None
@@ -543,9 +600,9 @@ def harness_block(a, model, dev, n_batches=24, warm=6):
 
     def loader():
         for b in range(n_batches + warm):
-            if b == warm + 1:      # run_images reads ONE batch ahead: batch warm + 1 is requested right before batch `warm` is processed
-                torch.cuda.synchronize(dev)
-                marks['t0'] = time.perf_counter()
+            if b == warm:          # run_images reads ONE batch ahead: batch `warm` is requested (and then packed) right before batch
+                torch.cuda.synchronize(dev)   # warm - 1 is processed.  The clock starts here: the pack AND the processing of every counted batch
+                marks['t0'] = time.perf_counter()   # are inside the region; so is the processing of batch warm - 1, which is NOT counted (conservative)
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
             yield imgs, [None] * a.batch, [{'image_id': b * a.batch + i} for i in range(a.batch)]
     results, ids = evaluate.run_images(args, loader(), model=model)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 2
+#define OG_ABI_VERSION 3
 
 #define OG_OK 0
 #define OG_EINVAL (-1)    /* bad argument (shape, k, alignment, null pointer)        */
@@ -164,13 +164,15 @@ int og_generate_limbs_flip_f32(const float *hmps_hr, const float *offs_pair, con
  * limbs (N,L,k,13) -> poses (N,mmax,n_kp,6) [x,y,v,scale,limb_score,global_idx],
  * counts int32[N] = poses per image, status int32[N] = 0 ok / 1 subset table overflowed
  * (more than `mmax` partial skeletons alive; results for that image are then invalid).
- * workspace: og_group_workspace_bytes(N, n_kp, mmax). */
+ * Any skeleton / top-k: the partial-skeleton table and, for large L*k, the staged candidate rows move from LDS to the
+ * workspace (L*k <= ~6 000 at mmax 128; OG_EUNSUPPORTED beyond).
+ * workspace: og_group_workspace_bytes(N, L, k, n_kp, mmax). */
 int og_greedy_group_f32(const float *limbs, int N, int L, int k, const int32_t *jf, const int32_t *jt,
                         int n_kp, double person_thre, float dist_max, int use_scale, int sort_dim, int mmax,
                         float *poses, int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes,
                         void *stream);
 
-size_t og_group_workspace_bytes(int N, int n_kp, int mmax);
+size_t og_group_workspace_bytes(int N, int L, int k, int n_kp, int mmax);
 
 /* ---- a4: PostProcess.flip_augment (vector-addition form)  decoder/factory.py:98-146 ----
  * hm (2N,C,h,w), off (2N,2L,h,w) -> hm_out (N,C,h,w), off_out (N,2L,h,w).
@@ -281,35 +283,17 @@ size_t og_conv2d_proj_workspace_bytes(int N, int Hin, int Win, int Cin, int Cout
  * for bit).  Replaces convolution.forward models/hourglass_104.py:26-30 and residual.forward :70-79 (BN folded), stride 1 or 2,
  * with the residual's 1x1 projection `skip` (:63-68) as extra K steps.
  *   og_conv_band_supported: 0 = not served (needs 64 <= Cin (and Cin2) <= 512 in multiples of 32, Cout % 16 == 0, stride 1 | 2,
- *     pad 1, input width <= 112, batch <= 64, a band's rows in 160 KiB of LDS); otherwise the number of workgroups of the launch.
+ *     pad 1, input width <= 112, a band's rows in 160 KiB of LDS); otherwise the number of workgroups of the launch.
  *   og_conv_band_pack_w16: w (Cout,3,3,Cin) = the memory of a channels_last (Cout,Cin,3,3) tensor [+ w2 (Cout,Cin2), or NULL with
  *     Cin2 = 0] -> packed, Cout * (9*Cin + Cin2) elements, once per layer.
  *   og_conv_band_*: x (N,Hin,Win,Cin), skip / out (N,H,W,Cout) with H = (Hin-1)/stride + 1, x2 (N,H2,W2,Cin2) sampled at
- *     (y*stride2, x*stride2) or NULL; bias fp32[Cout] (with a projection: the sum of both folded biases).
- *   og_conv_band_chain_*: n_layers (<= 16) DEPENDENT layers in one launch -- layers[l].x must be layers[l-1].out; skip / x2 may be
- *     the `out` of any earlier layer of the list or tensors complete before the launch; every `out` a distinct buffer; one batch
- *     size.  Layer l+1's weight fetch, launch boundary and set-up hide behind layer l (the bottom of the hourglass is a chain of
- *     ~5 us layers).  workspace: og_conv_band_chain_workspace_bytes() bytes, 128-byte aligned, ZERO before the first launch (the
- *     launch leaves it zero); its last int is a sticky error word (non-zero: a bounded wait inside a launch ran out -- results of
- *     that launch are invalid; never observed, kept so that a fault cannot hang the GPU).  Launches that share a workspace must be
- *     stream-ordered. */
-typedef struct OgBandLayerDesc {
-    const void *x, *w_packed;
-    const float *bias;
-    const void *skip, *x2;
-    void *out;
-    int N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2;
-} OgBandLayerDesc;
+ *     (y*stride2, x*stride2) or NULL; bias fp32[Cout] (with a projection: the sum of both folded biases). */
 int og_conv_band_supported(int N, int Hin, int Win, int Cin, int Cout, int stride, int H2, int W2, int Cin2, int stride2);
 int og_conv_band_pack_w16(const void *w, const void *w2, int Cin, int Cout, int Cin2, void *packed, void *stream);
-size_t og_conv_band_chain_workspace_bytes(void);
-int og_conv_band_chain_supported(const OgBandLayerDesc *layers, int n_layers);   /* 1 = og_conv_band_chain_* serves the list as one launch */
 int og_conv_band_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, const void *x2, void *out, int N,
                       int Hin, int Win, int Cin, int Cout, int stride, int relu, int H2, int W2, int Cin2, int stride2, void *stream);
 int og_conv_band_f16(const void *x, const void *w_packed, const float *bias, const void *skip, const void *x2, void *out, int N,
                      int Hin, int Win, int Cin, int Cout, int stride, int relu, int H2, int W2, int Cin2, int stride2, void *stream);
-int og_conv_band_chain_bf16(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
-int og_conv_band_chain_f16(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
 /* ---- the same 3x3 stride-1 convolution for the LARGE levels (160x160 / 80x80 / 40x40 at 640x640 input), on weights tiled
  * once in advance: csrc/conv3x3_tiled.inc -- halo-tiled direct convolution, two 4-wave workgroups per CU, 32-channel K steps,
  * every weight stage one contiguous 8 KiB LDS image.  Same arithmetic and epilogue as og_conv3x3_bf16 (fp32 accumulation, the
@@ -338,29 +322,6 @@ int og_conv3x3_tiled_bf16(const void *x, const void *w_packed, const float *bias
  * (N,H,W,Cout) tensor in between is never written.  Shapes and workspace as og_conv3x3_tiled_bf16. */
 int og_conv3x3_tiled_up2_bf16(const void *x, const void *w_packed, const float *bias, const void *skip, void *up, int N, int H,
                               int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream);
-/* Up to four DEPENDENT tiled 3x3 stride-1 layers (a residual's conv1 -> conv2, consecutive residuals: models/hourglass_104.py:50-79)
- * as ONE launch: the workgroups of layer l + 1 follow those of layer l in the grid and wait, tile by tile, for the pixel tiles of
- * layer l under their halo (one arrival counter per pixel tile) -- the partly filled last round of a layer's workgroups is filled
- * by the next layer instead of idling to a kernel boundary.  Results are bit-identical to the layer-wise calls.
- *   layers[l]: x (N,H,W,Cin) -> out (N,H,W,Cout) as og_conv3x3_tiled_bf16; layers[l].x is normally layers[l-1].out; skip may be any
- *     tensor complete before the launch or the output of an EARLIER layer of the list; `up` (see og_conv3x3_tiled_up2_bf16) only on
- *     the last layer (its `out` is then NULL).  All layers share N, H, W.
- *   og_conv3x3_tiled_chain_supported: 1 = the list is served (every layer a 16x16 or 40x4 tile shape without K split, workgroup
- *     counts multiples of 8, 2..4 layers).
- *   workspace: og_conv3x3_tiled_chain_workspace_bytes(), 256-byte aligned, ZERO-INITIALISED once by the caller; every launch leaves
- *     it zero (its last word is a sticky error word: a bounded wait ran out -- never observed).  Launches that share a workspace
- *     must be stream-ordered. */
-typedef struct OgTiledLayerDesc {
-    const void *x, *w_packed;
-    const float *bias;
-    const void *skip;
-    void *out, *up;
-    int N, H, W, Cin, Cout, relu;
-} OgTiledLayerDesc;
-size_t og_conv3x3_tiled_chain_workspace_bytes(void);
-int og_conv3x3_tiled_chain_supported(const OgTiledLayerDesc *layers, int n_layers);
-int og_conv3x3_tiled_chain_bf16(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
-int og_conv3x3_tiled_chain_f16(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream);
 /* Stride 2 (residual.conv1 of the down-sampling residuals, models/hourglass_104.py:54-57 with stride 2, and the second `pre`
  * layer :214-217) on the same kernel structure: x (N,Hin,Win,Cin) -> out (N,Hin/2,Win/2,Cout), pad 1; weights packed with
  * order 1; the four input-parity phases of a tile are gathered straight from the NHWC input by the LDS-DMA.
@@ -414,8 +375,6 @@ int og_conv2d_f16(const void *x, const void *w, const float *bias, const void *s
 int og_conv2d_proj_f16(const void *x, const void *w_cat, const float *bias, const void *x2, void *out, int N, int Hin,
                        int Win, int Cin, int Cout, int ksize, int stride, int H2, int W2, int Cin2, int stride2, int relu,
                        void *workspace, size_t workspace_bytes, void *stream);
-
-void og_conv3x3_debug_stamps(void *buf);
 
 /* ---- training losses, value + gradient in one pass ----
  * og_focal_l2_loss_f32: models/losses.py:31-58 + HeatMapsLoss :174-176.  pred/gt (N,C,hw) fp32, mask_miss

@@ -15,7 +15,7 @@ if os.environ.get("OG_DECODER_LIB"):  # alternative build of the same ABI (kerne
     LIB_PATH = os.environ["OG_DECODER_LIB"]
 
 OG_OK, OG_EINVAL, OG_ENOSPC, OG_EHIP, OG_EUNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 
@@ -41,7 +41,7 @@ SIGNATURES = {
                                    _i, _vp, _sz, _vp]),
     "og_generate_limbs_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "og_greedy_group_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "og_group_workspace_bytes": (_sz, [_i, _i, _i]),
+    "og_group_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "og_flip_merge_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_flip_cat_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_bias_act_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
@@ -60,13 +60,9 @@ SIGNATURES = {
     "og_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "og_conv2d_proj_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv2d_proj_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "og_conv3x3_debug_stamps": (None, [_vp]),
     "og_conv_band_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "og_conv_band_pack_w16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "og_conv_band_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "og_conv_band_chain_workspace_bytes": (_sz, []),
-    "og_conv_band_chain_supported": (_i, [_vp, _i]),
-    "og_conv_band_chain_bf16": (_i, [_vp, _i, _vp, _sz, _vp]),
     "og_conv3x3_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
     "og_conv3x3_pack_w16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "og_conv3x3s2_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
@@ -76,9 +72,6 @@ SIGNATURES = {
     "og_conv3x3_tiled_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "og_conv3x3_tiled_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv3x3_tiled_up2_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "og_conv3x3_tiled_chain_workspace_bytes": (_sz, []),
-    "og_conv3x3_tiled_chain_supported": (_i, [_vp, _i]),
-    "og_conv3x3_tiled_chain_bf16": (_i, [_vp, _i, _vp, _sz, _vp]),
     "og_encode_heatmaps_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "og_encode_jitter_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "og_encode_offsets_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -92,45 +85,6 @@ for _name in [n for n in SIGNATURES if n.endswith('_bf16')]:
 SIGNATURES['og_nhwc_f16_to_nchw_f32'] = SIGNATURES['og_nhwc_bf16_to_nchw_f32']
 
 _lib = None
-
-
-class BandLayerDesc(C.Structure):
-    """OgBandLayerDesc (include/og_decoder.h): one layer of an og_conv_band_chain_* launch."""
-    _fields_ = [("x", _vp), ("w_packed", _vp), ("bias", _vp), ("skip", _vp), ("x2", _vp), ("out", _vp),
-                ("N", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Cout", _i), ("stride", _i), ("relu", _i),
-                ("H2", _i), ("W2", _i), ("Cin2", _i), ("stride2", _i)]
-
-
-def band_chain_supported(descs):
-    arr = (BandLayerDesc * len(descs))(*descs)
-    return bool(load().og_conv_band_chain_supported(arr, len(descs)))
-
-
-def band_chain(descs, dtype, workspace, device):
-    """og_conv_band_chain_*: `descs` = list of BandLayerDesc (layer l reads layer l-1's output), `workspace` = a zero-initialised
-    uint8 tensor of og_conv_band_chain_workspace_bytes() (one per set of stream-ordered launches)."""
-    lib = load()
-    arr = (BandLayerDesc * len(descs))(*descs)
-    check(lp(lib, 'og_conv_band_chain', dtype)(arr, len(descs), ptr(workspace), workspace.numel(), stream_ptr(device)), lib)
-
-
-class TiledLayerDesc(C.Structure):
-    """OgTiledLayerDesc (include/og_decoder.h): one layer of an og_conv3x3_tiled_chain_* launch."""
-    _fields_ = [("x", _vp), ("w_packed", _vp), ("bias", _vp), ("skip", _vp), ("out", _vp), ("up", _vp),
-                ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("relu", _i)]
-
-
-def tiled_chain_supported(descs):
-    arr = (TiledLayerDesc * len(descs))(*descs)
-    return bool(load().og_conv3x3_tiled_chain_supported(arr, len(descs)))
-
-
-def tiled_chain(descs, dtype, workspace, device):
-    """og_conv3x3_tiled_chain_*: `descs` = list of TiledLayerDesc (2..4 dependent layers), `workspace` = a zero-initialised uint8
-    tensor of og_conv3x3_tiled_chain_workspace_bytes() (one per set of stream-ordered launches)."""
-    lib = load()
-    arr = (TiledLayerDesc * len(descs))(*descs)
-    check(lp(lib, 'og_conv3x3_tiled_chain', dtype)(arr, len(descs), ptr(workspace), workspace.numel(), stream_ptr(device)), lib)
 
 
 def lp(lib, stem, dtype):
@@ -152,11 +106,14 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -m offsetguided_amd.build` "
                 "(hipcc --offload-arch=gfx950).  offsetguided_amd has no CPU/torch fallback.")
         lib = C.CDLL(LIB_PATH)
+        # the version first: a stale library would otherwise fail on a missing symbol with a bare AttributeError
+        lib.og_abi_version.restype, lib.og_abi_version.argtypes = _i, []
+        if lib.og_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.og_abi_version()} != {ABI_VERSION}; rebuild with "
+                              "`python -m offsetguided_amd.build --force`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.og_abi_version() != ABI_VERSION:
-            raise ImportError(f"{LIB_PATH}: ABI version {lib.og_abi_version()} != {ABI_VERSION}; rebuild")
         _lib = lib
     return _lib
 

@@ -67,11 +67,22 @@ struct ConvArgs {
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
 };
 
+// diagnostic builds only (tools/build_variants.sh conv3x3.hip stamps "-DOG_DEBUG_STAMPS"; -DOG_TILED_STAMPS / -DOG_PW_STAMPS imply it):
+// the product library has neither the marks nor og_conv3x3_debug_stamps
+#if defined(OG_TILED_STAMPS) || defined(OG_PW_STAMPS)
+#ifndef OG_DEBUG_STAMPS
+#define OG_DEBUG_STAMPS 1
+#endif
+#endif
+#ifdef OG_DEBUG_STAMPS
 #define CONV_STAMP(i)                                                                                         \
     do {                                                                                                      \
         if (a.stamps && tid == 0)                                                                             \
             a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#else
+#define CONV_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return f2lp(f); }   // (bf16, or fp16 in the -DOG_DT_F16 build)
 __device__ __forceinline__ float bf2f(unsigned short u) { return lp2f(u); }
@@ -489,13 +500,15 @@ static unsigned long long *g_stamps = nullptr;
 
 }  // namespace
 
-// Debug aid (tools/conv_bench.py --stamps): device buffer of [workgroups][8] u64 that later launches fill with
-// s_memrealtime marks; pass NULL to switch off.  Not part of the product path.
 static inline int conv_out_dim(int in, int ksize, int stride) { return (in + 2 * (ksize / 2) - ksize) / stride + 1; }
 
 // entry points that do not depend on the 16-bit type exist once in the library: defined by the bf16 build only
 #ifndef OG_DT_F16
+#ifdef OG_DEBUG_STAMPS
+// Debug aid of the diagnostic builds (tools/conv_bench.py --stamps, tools/c1_stamps.py, tools/pw_stamps.py): device buffer of
+// [workgroups][8] u64 that later launches fill with s_memrealtime marks; NULL switches it off.  Not in the product library.
 OG_API void og_conv3x3_debug_stamps(void *buf) { g_stamps = (unsigned long long *)buf; }
+#endif
 
 OG_API size_t og_conv3x3_workspace_bytes(long pixels, int Cin, int Cout)
 {
@@ -756,87 +769,6 @@ OG_API int OG_LP_NAME(og_conv3x3_tiled_up2)(const void *x, const void *w_packed,
     OG_REQUIRE(up, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE((long)N * H * W * 4 * Cout < (1l << 30), OG_EUNSUPPORTED, "%s: tensor too large (>= 2 GiB)", name);
     return conv3x3_tiled_impl(name, x, w_packed, bias, skip, nullptr, up, N, H, W, Cin, Cout, relu, workspace, workspace_bytes, stream);
-}
-
-// ---- chained launch of dependent tiled layers (conv3x3_tiled_chain_kernel) ----
-namespace {
-constexpr size_t kChainWsBytes = (size_t)(3 * kChainMaxTiles + 64) * sizeof(int);
-// 0 = not served; else the tile kind all layers share.  Fills the launch arguments when `c` is given.
-int tiled_chain_plan(const OgTiledLayerDesc *L, int n, TiledChainArgs *c)
-{
-    if (!L || n < 2 || n > 4) return 0;
-    int kind0 = 0;
-    long first = 0;
-    for (int l = 0; l < n; ++l) {
-        const OgTiledLayerDesc &d = L[l];
-        if (!d.x || !d.w_packed || !d.bias || d.N <= 0 || d.H <= 0 || d.W <= 0) return 0;
-        if (d.N != L[0].N || d.H != L[0].H || d.W != L[0].W) return 0;
-        if (l + 1 < n ? (d.up != nullptr || !d.out) : !(d.out || d.up)) return 0;
-        if (d.up && (uintptr_t)d.up % 16) return 0;
-        const long M = (long)d.N * d.H * d.W;
-        if (M * d.Cin >= (1l << 30) || M * d.Cout >= (1l << 30)) return 0;
-        const int kind = tiled_kind(d.H, d.W, d.Cin, d.Cout);
-        if ((kind != 1 && kind != 2) || (kind0 && kind != kind0)) return 0;
-        kind0 = kind;
-        const long items = tiled_items(kind, d.N, d.H, d.W, d.Cout);
-        if (items % 8 || items > (long)kMaxTiles || tiled_ksplit(kind, items, d.Cin) != 1) return 0;
-        if (items / (d.Cout / 128) > kChainMaxTiles) return 0;
-        if (c) {
-            ConvArgs &h = c->layer[l];
-            h = ConvArgs{};
-            h.x = (const unsigned short *)d.x; h.w = (const unsigned short *)d.w_packed; h.bias = d.bias;
-            h.skip = (const unsigned short *)d.skip; h.out = (unsigned short *)d.out; h.up = (unsigned short *)d.up;
-            h.N = d.N; h.H = d.H; h.W = d.W; h.Cin = d.Cin; h.Cout = d.Cout; h.M = (int)M; h.n_tiles = d.Cout / 128; h.relu = d.relu;
-            h.Hin = d.H; h.Win = d.W; h.stride = 1; h.taps = 9; h.ksplit = 1;
-            h.x_bytes = (int)(M * d.Cin * 2);
-            h.w_bytes = d.Cout * 9 * d.Cin * 2;
-            c->first[l] = (int)first;
-            c->counters_per_layer = (int)(items / (d.Cout / 128));
-        }
-        first += items;
-    }
-    if (first >= (1l << 30)) return 0;
-    if (c) {
-        for (int l = n; l <= 4; ++l) c->first[l] = (int)first;
-        c->n = n;
-    }
-    return kind0;
-}
-}  // namespace
-
-#ifndef OG_DT_F16
-OG_API size_t og_conv3x3_tiled_chain_workspace_bytes(void) { return kChainWsBytes; }
-OG_API int og_conv3x3_tiled_chain_supported(const OgTiledLayerDesc *layers, int n_layers) { return tiled_chain_plan(layers, n_layers, nullptr) ? 1 : 0; }
-#endif
-
-OG_API int OG_LP_NAME(og_conv3x3_tiled_chain)(const OgTiledLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream)
-{
-    const char *name = OG_LP_STR("og_conv3x3_tiled_chain");
-    OG_REQUIRE(layers && workspace, OG_EINVAL, "%s: null pointer", name);
-    OG_REQUIRE(workspace_bytes >= kChainWsBytes, OG_ENOSPC, "%s: workspace %zu < %zu bytes (og_conv3x3_tiled_chain_workspace_bytes)", name,
-               workspace_bytes, kChainWsBytes);
-    OG_REQUIRE((uintptr_t)workspace % 256 == 0, OG_EINVAL, "%s: workspace must be 256-byte aligned", name);
-    TiledChainArgs c = {};
-    const int kind = tiled_chain_plan(layers, n_layers, &c);
-    OG_REQUIRE(kind != 0, OG_EUNSUPPORTED, "%s: the list is not served as one launch (og_conv3x3_tiled_chain_supported)", name);
-    // [3 x kChainMaxTiles arrival counters (a launch uses the first (n - 1) x its tiles of them) | exit count | error word | pad]
-    c.counters = (int *)workspace;
-    hipStream_t st = (hipStream_t)stream;
-#define TILED_CHAIN_LAUNCH(TW_, TH_, WM_)                                                                              \
-    do {                                                                                                               \
-        constexpr int halo_ = ((TW_ + 2) * (TH_ + 2) * 5 * 16 + 1023) / 1024 * 1024;                                   \
-        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024;                                                              \
-        static OgAttrOnce attr_;                                                                                       \
-        if (attr_.need())                                                                                              \
-            (void)hipFuncSetAttribute((const void *)conv3x3_tiled_chain_kernel<TW_, TH_, WM_, 2>,                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-        hipLaunchKernelGGL((conv3x3_tiled_chain_kernel<TW_, TH_, WM_, 2>), dim3((unsigned)c.first[4]), dim3(256), lds_, st, c); \
-    } while (0)
-    if (kind == 1) TILED_CHAIN_LAUNCH(16, 16, 4);
-    else TILED_CHAIN_LAUNCH(40, 4, 2);
-#undef TILED_CHAIN_LAUNCH
-    OG_LAUNCH_CHECK(name);
-    return OG_OK;
 }
 
 OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, const float *bias, const void *skip, void *out,

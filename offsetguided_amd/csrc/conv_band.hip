@@ -1,6 +1,6 @@
 // Band-resident 3x3 convolution (+ optional 1x1 projection along K) for the small hourglass levels: 20x20, 10x10 and 5x5 at
 // batch 8 (convolution.forward models/hourglass_104.py:26-30, residual.forward :70-79, the bottom of kp_module :183-190),
-// one layer per launch (og_conv_band_*) or a CHAIN of dependent layers in one launch (og_conv_band_chain_*).
+// one layer per launch (og_conv_band_*).
 //
 // Why another kernel: those layers are GEMMs with M = 25 ... 400 pixels per image against K = 9*Cin = 3456 ... 4608.  The split-K
 // kernel of csrc/conv3x3.hip spends 61 % of a 13 us layer outside its K loop (set-up, fp32 slab publish, arrival ticket,
@@ -18,18 +18,9 @@
 //     leaves through the fused bias / residual / ReLU epilogue as 8-byte stores (4 couts of one pixel per lane).
 // Work is XCD-aware: the workgroups that share a weight slice (same couts, different images / bands) run on one XCD, so a
 // slice crosses the fabric once per layer (speed only: no result depends on the placement).
-//
-// Chained form: a launch walks a list of layers, layer l reading what layer l-1 wrote.  Roles (layer, couts, image, band) are
-// handed out through per-(layer, XCD) ticket counters; a workgroup draws its ticket for layer l+1 while it works on layer l and
-// requests that role's weights as soon as its MFMAs of layer l have consumed the old ones; only then does it wait for the
-// per-image completion counter of layer l -- the weight fetch, the launch boundary and the set-up of a layer disappear behind
-// the layer before it.  Deadlock-free under ANY residency (no cooperative launch, other kernels may hold CUs): before a
-// workgroup waits for layer l it has seen every role of layer l taken, taking the untaken ones (of any XCD) itself; a role's
-// holder is running by construction, so the smallest unfinished layer always makes progress.  Hand-off as MI355X_MICROARCH.md
-// "inter-workgroup visibility", first measured row: write-through (sc1) stores, every storing wave's vmcnt(0), workgroup
-// barrier, ONE lane's agent-scope add; the consumer's single lane polls with sc1 loads, a workgroup barrier follows, every
-// load of handed-off bytes is an sc1 load to registers.  Every spin is bounded (a time-out raises the launch's error word
-// and goes on: wrong numbers, never a hang).
+// (A chained persistent form -- a run of dependent layers as ONE launch with ticket queues and per-image completion counters --
+// was built and measured in round 4: 7.4 instead of 8.2 us per 5x5 layer alone, +1..4 % per step in the network because it holds
+// all 256 CUs; it lives in tools/experiments/conv_band_chain.patch, not in the product.)
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -45,10 +36,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t kOob = 0x80000000u;   // per-lane buffer offset beyond any tensor this library accepts (< 2 GiB): reads as 0
 constexpr int kWaves = 4;                // one per SIMD
-constexpr int kMaxLayers = 16;           // layers of a chained launch (kernel arguments: 16 x 152 B)
-constexpr int kMaxImages = 64;
-constexpr int kSyncStride = 32;          // ints per counter: one 128-byte line each
-constexpr int kMaxLds = 160 * 1024 - 64; // LDS plan limit (the chained kernel keeps two words behind the plan's bytes)
+constexpr int kMaxLds = 160 * 1024 - 64; // LDS plan limit
 
 struct BandLayer {
     const unsigned short *x;     // (N,Hin,Win,Cin)
@@ -65,7 +53,6 @@ struct BandLayer {
     int x2_off, sb_off;          // LDS byte offsets of the x2 image and of the epilogue operands (residual slice + biases)
     int w_bytes;
     int kw, kw2;                 // 32-channel chunks per wave: ceil(Cin / 32 / 4), ceil(Cin2 / 32 / 4)
-    int in_chain;                // chained launch: bit 0 = x, bit 1 = skip, bit 2 = x2 was written by an earlier layer of THIS launch
     uint32_t magic_p;            // ceil(2^32 / (Win + 1))
 };
 
@@ -80,10 +67,9 @@ struct BandLayer {
 
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
 
-template <bool SC1>
 __device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, SC1 ? 16 : 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, int bytes)
@@ -105,7 +91,7 @@ __device__ __forceinline__ void band_load_weights(const BandLayer &a, int g, u32
         const int ch = wave * a.kw + k;
         const uint32_t voff = (k < a.kw && ch < nch) ? (uint32_t)(lane << 4) : kOob;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wf[k][tap] = load16<false>(wr, voff, (uint32_t)(((g * nch + ch) * 9 + tap) << 10));
+        for (int tap = 0; tap < 9; ++tap) wf[k][tap] = load16(wr, voff, (uint32_t)(((g * nch + ch) * 9 + tap) << 10));
     }
     if (KW2 > 0) {
         const uint32_t proj_base = (uint32_t)a.Cout * 9u * (uint32_t)a.Cin * 2u;
@@ -113,7 +99,7 @@ __device__ __forceinline__ void band_load_weights(const BandLayer &a, int g, u32
         for (int k = 0; k < KW2; ++k) {
             const int ch = wave * a.kw2 + k;
             const uint32_t voff = (a.x2 && k < a.kw2 && ch < nch2) ? (uint32_t)(lane << 4) : kOob;
-            wp[k] = load16<false>(wr, voff, proj_base + (uint32_t)((g * nch2 + ch) << 10));
+            wp[k] = load16(wr, voff, proj_base + (uint32_t)((g * nch2 + ch) << 10));
         }
     }
 }
@@ -122,8 +108,8 @@ __device__ __forceinline__ void band_load_weights(const BandLayer &a, int g, u32
 __device__ __forceinline__ int xcc_id_dbg() { return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 15u); }
 #endif
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: behind a weight prefetch every barrier
-// would wait for ~40 KiB from HBM (3 us per layer of the chained form, measured).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the weight loads issued at kernel entry
+// (~40 KiB per workgroup) would have to land before the first barrier instead of before the first MFMA.
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -131,42 +117,19 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt()
-{
-    // simm16 = vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt(15) << 8 | vmcnt[5:4] << 14
-    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-    asm volatile("" ::: "memory");
-}
-
-// One role: layer `a`, cout tile g, work item (image, band), on a workgroup of EIGHT waves with fixed parts:
-//   waves 0-3, the COMPUTE waves (one per SIMD): hold the weight slices (requested by the caller: band_load_weights), run the
-//     MFMAs, exchange the partial tiles, run the epilogue and store; the only loads they ever issue are weights;
-//   waves 4-7, the LOADER waves: zero the border pixels, wait for the layer before (chained form), stage the input rows, the
-//     projection's pixels and the residual / bias operands of the epilogue into LDS; their first lane draws tickets and signals.
-// Why the split: vector memory operations of a wave retire in issue order.  A wave that has just requested 40 KiB of weights
-// for the NEXT layer cannot see a poll, a staged pixel or an epilogue operand of THIS layer before those have landed; with
-// the parts split, a prefetch only ever sits in front of the compute waves' own stores, and they order it behind them.
-// PT: 16-position column blocks per band (2, 4 or 7); KW / KW2: 32-channel chunks per compute wave of the 3x3 operand / of the
-// projection (compile-time upper bounds, a.kw / a.kw2 are the layer's); CHAIN: see the file header (wait_word / wait_target:
-// completion counter of the layer before, or null).  hook(1) runs (all threads) behind the barrier that precedes the MFMAs,
-// hook(2) / hook(3) in front of / behind the barrier that follows them; after_stores() runs behind the completion signal (the
-// chained kernel requests the next role's weights there).
-template <int PT, int KW, int KW2, bool CHAIN, typename F1, typename F2>
+// One work item: layer `a`, cout tile g, (image, band), on a workgroup of FOUR waves (one per SIMD, <= 256 registers: the
+// workgroup shares its CU with the kernels that run beside it in the network).  The waves first stage the band -- zero the border
+// pixels, the input rows, the projection's pixels, the residual / bias operands of the epilogue -- then run the MFMAs on their K
+// slices (weights requested by the caller: band_load_weights), exchange the partial tiles, run the epilogue and store.
+// PT: 16-position column blocks per band (2, 4 or 7); KW / KW2: 32-channel chunks per wave of the 3x3 operand / of the
+// projection (compile-time upper bounds, a.kw / a.kw2 are the layer's).
+template <int PT, int KW, int KW2>
 __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u32x4 (&wf)[KW][9], u32x4 (&wp)[KW2 > 0 ? KW2 : 1],
-                                          unsigned char *lds, const int *wait_word, int wait_target, int *done_word, int *error_word,
-                                          unsigned long long *stamps, F1 hook, F2 after_stores)
+                                          unsigned char *lds, unsigned long long *stamps)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // CHAIN: eight waves with fixed parts (above).  One layer per launch: FOUR waves that play both parts one after the other --
-    // nothing is prefetched there, and a 4-wave workgroup (one wave per SIMD, <= 256 registers) can share its CU with a
-    // workgroup of the kernels that run beside it in the network (the 8-wave form owns the CU: every such launch then waits
-    // for the 20x20 convolution of the up1 branch beside it, +0.2 ms per forward)
-    const bool cw = CHAIN ? wave < kWaves : true;              // compute wave
-    const bool lw = CHAIN ? wave >= kWaves : true;             // loader wave
-    const int ltid = CHAIN ? tid - kWaves * 64 : tid;          // loader thread 0 .. 255
-    const int lwave = CHAIN ? wave - kWaves : wave;
+    const int ltid = tid, lwave = wave;
     const int nch = a.Cin >> 5, nch2 = a.Cin2 >> 5;
     const int img = item / a.bands, band = item - img * a.bands;
     const int y0 = band * a.band_rows, rows = min(a.band_rows, a.H - y0);
@@ -174,7 +137,6 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     const int NR = (rows - 1) * a.stride + 3;      // LDS rows: input rows y0*stride-1 .. (y0+rows-1)*stride+1 (zeros outside the image)
     const int ri0 = y0 * a.stride - 1;
     const int Q = rows * P - 1;                    // output positions of the band (the zero pixels between rows included)
-    const bool x_chain = CHAIN && (a.in_chain & 1), skip_chain = CHAIN && (a.in_chain & 2), x2_chain = CHAIN && (a.in_chain & 4);
     const bool has_proj = KW2 > 0 && a.x2 != nullptr;
 #ifdef OG_BAND_STAMPS
 #define LSTAMP(i) do { if (stamps && ltid == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -185,7 +147,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
 #endif
     LSTAMP(0);
 
-    if (lw) {
+    {
         // ---- zero pixels of the LDS image: the leading pixel, the pixel behind every row, the rows outside the image
         const int slots = a.pitch >> 4;            // 16-byte slots per pixel
         for (int s = ltid; s < (NR + 1) * slots; s += kWaves * 64) {
@@ -198,26 +160,10 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
         if (ri0 + NR - 1 >= a.Hin)
             for (int s = ltid; s < a.Win * slots; s += kWaves * 64)
                 *reinterpret_cast<u32x4 *>(lds + (1 + (NR - 1) * P) * a.pitch + (s << 4)) = (u32x4){0, 0, 0, 0};
-        // ---- chained form: the layer before must be complete for this image (one lane polls, bounded; the barrier below
-        // brings the news to the other waves)
-        if (CHAIN && wait_word && ltid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) {
-                    __hip_atomic_store(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
     }
-    // (All eight waves meet here.  Letting only the loader waves meet -- through an LDS word, the compute waves still issuing
-    // their weight prefetch -- was measured: 30 us per layer instead of 7.5; the two streams of loads then interleave in the
-    // CU's one vector memory pipe, EXPERIMENTS.md)
-    if (CHAIN && wait_word) lds_barrier();
     LSTAMP(1);
 
-    if (lw) {
+    {
         // ---- activations: whole pixels, one per wave instruction (Cin / 8 <= 64 lanes x 16 B), into the padded LDS image
         {
             const int r_lo = max(ri0, 0), r_hi = min(ri0 + NR - 1, a.Hin - 1);      // input rows that exist
@@ -233,7 +179,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
                 for (int i = 0; i < SB; ++i) {
                     const int p = p0 + i * kWaves;
                     const uint32_t vo = (lane_on && p < npix) ? (uint32_t)((lane << 4) + p * a.Cin * 2) : kOob;
-                    v[i] = x_chain ? load16<true>(xr, vo, 0) : load16<false>(xr, vo, 0);
+                    v[i] = load16(xr, vo, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
@@ -256,7 +202,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
                     const int y = (int)div_magic((uint32_t)q, a.magic_p), x = q - y * P;
                     const bool ok = lane_on && q < Q && x < a.W;
                     const uint32_t vo = ok ? (uint32_t)(((((img * a.H2 + (y0 + y) * a.stride2) * a.W2 + x * a.stride2) * a.Cin2) << 1) + (lane << 4)) : kOob;
-                    v[i] = x2_chain ? load16<true>(x2r, vo, 0) : load16<false>(x2r, vo, 0);
+                    v[i] = load16(x2r, vo, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
@@ -273,7 +219,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
                 const int y = (int)div_magic((uint32_t)q, a.magic_p), x = q - y * P;
                 const bool ok = a.skip && q < Q && x < a.W;
                 const uint32_t vo = ok ? (uint32_t)(((((img * a.H + y0 + y) * a.W + x) * a.Cout + g * 16 + (s & 1) * 8)) << 1) : kOob;
-                const u32x4 v = skip_chain ? load16<true>(sr, vo, 0) : load16<false>(sr, vo, 0);
+                const u32x4 v = load16(sr, vo, 0);
                 *reinterpret_cast<u32x4 *>(lds + a.sb_off + (s << 4)) = v;
             }
             if (ltid < 4) *reinterpret_cast<f32x4 *>(lds + a.sb_off + PT * 512 + (ltid << 4)) = *reinterpret_cast<const f32x4 *>(a.bias + g * 16 + ltid * 4);
@@ -281,7 +227,6 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     }
     LSTAMP(2);
     lds_barrier();
-    hook(1);             // (loader waves are idle from here to the end of the role)
 
     // ---- MFMA: position q = 16 t + column reads LDS pixel 1 + P + stride*q + (dy*P + dx).  Fragment reads run D steps ahead of
     // the MFMAs that consume them (sched_barrier: left alone, hipcc sinks every read in front of its MFMA -- one read in flight,
@@ -290,7 +235,7 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     f32x4 acc[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (cw) {
+    {
         constexpr int D = PT >= 7 ? 1 : PT == 4 ? 2 : 3, NB = D + 1, NS = KW * 9;
         int base[PT];
 #pragma unroll
@@ -337,18 +282,13 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
     CSTAMP(3);
 
     // ---- the four partial tiles meet in LDS: [wave][t][lane] float4 over the (dead) staged input
-    hook(2);
     lds_barrier();
-    hook(3);
-    if (cw) {
 #pragma unroll
-        for (int t = 0; t < PT; ++t) *reinterpret_cast<f32x4 *>(lds + (((wave * PT + t) << 6) + lane) * 16) = acc[t];
-    }
+    for (int t = 0; t < PT; ++t) *reinterpret_cast<f32x4 *>(lds + (((wave * PT + t) << 6) + lane) * 16) = acc[t];
     lds_barrier();
     CSTAMP(4);
-    if (cw) {
+    {
         // epilogue: thread o owns 4 couts of one output position (PT = 7: 448 owners on 256 threads)
-        const __amdgpu_buffer_rsrc_t orr = rsrc_of(a.out, a.N * a.H * a.W * a.Cout * 2);
 #pragma unroll
         for (int rep = 0; rep < (PT > 4 ? 2 : 1); ++rep) {
             const int o = tid + rep * kWaves * 64, l = o & 63, t = o >> 6;
@@ -371,30 +311,15 @@ __device__ __forceinline__ void band_role(const BandLayer &a, int g, int item, u
                 ov[0] = (uint32_t)f2lp(v[0]) | ((uint32_t)f2lp(v[1]) << 16);
                 ov[1] = (uint32_t)f2lp(v[2]) | ((uint32_t)f2lp(v[3]) << 16);
                 const size_t oidx = ((size_t)(img * a.H + y0 + y) * a.W + x) * a.Cout + g * 16 + (l >> 4) * 4;
-                if (CHAIN) __builtin_amdgcn_raw_buffer_store_b64(ov, orr, (uint32_t)(oidx << 1), 0, 16);     // write-through
-                else *reinterpret_cast<u32x2 *>(a.out + oidx) = ov;
+                *reinterpret_cast<u32x2 *>(a.out + oidx) = ov;
             }
         }
     }
     CSTAMP(5);
-    if (CHAIN) {
-        // every storing wave drains its write-through stores, the workgroup meets, ONE lane signals
-        wait_vmcnt<0>();
-        lds_barrier();            // (also: every wave is done reading the partial tiles -- the next role may write the LDS)
-        if (ltid == 0 && done_word) __hip_atomic_fetch_add(done_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        LSTAMP(6);
-        // The next role's weights are requested only now: issued in front of the drain (younger than the stores, counted
-        // vmcnt) they delayed the stores' acknowledgements by the whole fetch (2.7 us per layer: the write-through stores and
-        // 37 MB of weight reads share the path to the memory side); behind the signal they still have the poll, the staging
-        // and the barriers of the next role (4 us) to land
-        after_stores();
-    } else {
-        (void)after_stores;
 #ifdef OG_BAND_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CSTAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CSTAMP(6);
 #endif
-    }
 #undef LSTAMP
 #undef CSTAMP
 }
@@ -410,149 +335,7 @@ conv_band_kernel(BandLayer a, unsigned long long *stamps)
     const int g = wid / items;
     u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
     band_load_weights<KW, KW2>(a, g, wf, wp);
-    band_role<PT, KW, KW2, false>(a, g, wid - g * items, wf, wp, lds, nullptr, 0, nullptr, nullptr,
-                                  stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr, [](int) {}, [] {});
-}
-
-struct ChainArgs {
-    BandLayer layer[kMaxLayers];
-    int n_layers;
-    int word_off;       // LDS byte offset of the kernel's four broadcast words (behind every layer's plan)
-    int *sync;          // [tickets: kMaxLayers x 8][done: kMaxLayers x kMaxImages][exited][error], kSyncStride ints each
-};
-
-__device__ __forceinline__ int xcc_id()
-{
-    return (int)(__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
-}
-
-// Roles of XCD x in layer `a`: the cout tiles g = x, x + 8, ... times every work item; ticket t -> (g = x + 8 * (t / items), item)
-__device__ __forceinline__ int xcd_roles(const BandLayer &a, int x) { return ((a.groups - x + 7) >> 3) * a.N * a.bands; }
-
-template <int PT, int KW, int KW2>
-__global__ void __launch_bounds__(2 * kWaves * 64)
-conv_band_chain_kernel(ChainArgs c, unsigned long long *stamps)
-{
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    int *const s_word = reinterpret_cast<int *>(lds + c.word_off);   // (static LDS beside 1024-aligned dynamic LDS would cost 1 KiB)
-    const int tid = threadIdx.x;
-    const bool cw = tid < kWaves * 64;             // compute wave; thread kWaves * 64 (first loader lane) is the control thread
-    const bool ctl = tid == kWaves * 64;
-    const int L = c.n_layers;
-    int *const tickets = c.sync, *const done = c.sync + kMaxLayers * 8 * kSyncStride;
-    int *const exited = done + kMaxLayers * kMaxImages * kSyncStride, *const error = exited + kSyncStride;
-    const int x = xcc_id();
-    u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
-    auto take = [&](int l, int xx) {       // every thread gets the ticket the control thread drew
-        if (ctl) s_word[0] = __hip_atomic_fetch_add(tickets + (l * 8 + xx) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds_barrier();
-        const int t = s_word[0];
-        lds_barrier();
-        return t;
-    };
-    auto role_g = [&](int l, int xx, int t) { return xx + 8 * (t / (c.layer[l].N * c.layer[l].bands)); };
-    auto wait_of = [&](int l, int img) { return l > 0 ? done + ((l - 1) * kMaxImages + img) * kSyncStride : (int *)nullptr; };
-    auto stamp_of = [&](int l, int xx, int t) { return stamps ? stamps + ((size_t)l * 4096 + (size_t)(xx * 512 + (t & 511))) * 8 : (unsigned long long *)nullptr; };
-
-    // Every layer's descriptor (three 64-byte lines of kernel arguments each, in device memory) is pulled into the scalar cache
-    // NOW, all requests in flight together: first touched at the top of its layer, the misses cost every workgroup ~2 us per
-    // layer (measured: every role entered 3 us behind its predecessor's signal)
-    {
-        int acc = 0;
-        const int *tab = reinterpret_cast<const int *>(&c.layer[0]);
-        for (int i = 0; i < L * (int)(sizeof(BandLayer) / 4); i += 16) acc ^= tab[i];
-        asm volatile("" ::"s"(acc));
-    }
-    // Tickets run TWO layers ahead: the draw for layer l+2 (and the look at layer l+1's counters, see below) is issued by the
-    // control thread while the compute waves run layer l's MFMAs -- the loader waves have nothing to do then -- and is read one
-    // role later.  Issued at the top of a role instead, the returning atomic was still in flight when the role's address
-    // arithmetic reused its destination register, and hipcc's guard (s_waitcnt vmcnt(0)) stalled the control wave for the
-    // atomic's round trip: 3-4 us per layer, every role entered that much behind its predecessor's signal.
-    int t_cur = take(0, x);
-    int t_next = L > 1 ? take(1, x) : 0x7fffffff;
-    bool open_cur = true, have_w = false;      // open_cur: layer l may still have roles nobody took (layer 0: unknown)
-    const bool peeker = tid >= kWaves * 64 && tid < kWaves * 64 + 8;
-    for (int l = 0; l < L; ++l) {
-        const BandLayer &a = c.layer[l];
-        int t_draw = 0x7fffffff, peek = 0x7fffffff, t_next2 = 0x7fffffff;
-        bool open_next = true;
-        auto hook = [&](int point) {
-            if (point == 1) {                 // the MFMAs start: draw for layer l+2, look at layer l+1's counters
-                if (l + 2 < L && ctl)
-                    t_draw = __hip_atomic_fetch_add(tickets + ((l + 2) * 8 + x) * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (l + 1 < L && peeker)
-                    peek = __hip_atomic_load(tickets + ((l + 1) * 8 + ((x + tid) & 7)) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (point == 2) {          // every wave retires them here (pending on some path, hipcc guards the first reuse
-                asm volatile("" ::"v"(t_draw), "v"(peek));     // of their registers with a vmcnt(0)); the control wave publishes
-                if (tid >= kWaves * 64 && tid < kWaves * 64 + 64) {
-                    const unsigned long long m = __ballot(l + 1 < L && peeker && peek < xcd_roles(c.layer[l + 1 < L ? l + 1 : l], (x + tid) & 7));
-                    if (ctl) { s_word[0] = t_draw; s_word[1] = m != 0; }
-                }
-            } else if (point == 3) {
-                t_next2 = s_word[0];
-                open_next = s_word[1] != 0;
-            }
-        };
-        if (t_cur < xcd_roles(a, x)) {
-            const int items = a.N * a.bands, g = role_g(l, x, t_cur), item = t_cur % items, img = item / a.bands;
-            if (!have_w && cw) band_load_weights<KW, KW2>(a, g, wf, wp);
-            have_w = false;
-            band_role<PT, KW, KW2, true>(
-                a, g, item, wf, wp, lds, wait_of(l, img), l > 0 ? c.layer[l - 1].groups * c.layer[l - 1].bands : 0,
-                done + (l * kMaxImages + img) * kSyncStride, error, stamp_of(l, x, t_cur), hook,
-                [&] {
-                    if (l + 1 < L && t_next < xcd_roles(c.layer[l + 1], x)) {
-                        if (cw) band_load_weights<KW, KW2>(c.layer[l + 1], role_g(l + 1, x, t_next), wf, wp);
-                        have_w = true;
-                    }
-                });
-        } else {
-            hook(1);
-            hook(2);
-            lds_barrier();
-            hook(3);
-            lds_barrier();
-        }
-        // Before anybody here may wait for layer l to complete, every role of layer l must have a (running) holder: take what
-        // is left in any XCD's queue (workgroups that are not resident).  One wave instruction looks at the eight counters.  In
-        // the common case the look during layer l-1 has already found every role of layer l taken.
-        while (open_cur) {
-            if (tid >= kWaves * 64 && tid < kWaves * 64 + 64) {
-                const int i = tid - kWaves * 64, xx = (x + i) & 7;
-                const bool open = i < 8 &&
-                                  __hip_atomic_load(tickets + (l * 8 + xx) * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < xcd_roles(a, xx);
-                const unsigned long long m = __ballot(open);
-                if (ctl) s_word[1] = m ? ((x + __builtin_ctzll(m)) & 7) : -1;
-            }
-            lds_barrier();
-            const int xx = s_word[1];
-            lds_barrier();
-            if (xx < 0) break;
-            const int t = take(l, xx);
-            if (t < xcd_roles(a, xx)) {
-                const int items = a.N * a.bands, item = t % items, img = item / a.bands;
-                if (cw) band_load_weights<KW, KW2>(a, role_g(l, xx, t), wf, wp);       // (this overwrites a prefetched slice: reloaded below)
-                have_w = false;
-                band_role<PT, KW, KW2, true>(a, role_g(l, xx, t), item, wf, wp, lds, wait_of(l, img),
-                                             l > 0 ? c.layer[l - 1].groups * c.layer[l - 1].bands : 0,
-                                             done + (l * kMaxImages + img) * kSyncStride, error, stamp_of(l, xx, t), [](int) {}, [] {});
-            }
-        }
-        t_cur = t_next;
-        t_next = t_next2;
-        open_cur = open_next;
-    }
-    // the last workgroup out clears the launch's words for the next launch (everybody else has stopped touching them)
-    if (ctl) {
-        const int n = __hip_atomic_fetch_add(exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == (int)gridDim.x - 1) {
-            for (int l = 0; l < L; ++l) {
-                for (int xx = 0; xx < 8; ++xx) __hip_atomic_store(tickets + (l * 8 + xx) * kSyncStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int i = 0; i < c.layer[l].N; ++i) __hip_atomic_store(done + (l * kMaxImages + i) * kSyncStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    band_role<PT, KW, KW2>(a, g, wid - g * items, wf, wp, lds, stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr);
 }
 
 // OHWI weights (the memory order of a channels_last (Cout,Cin,3,3) tensor) [+ the projection's (Cout,Cin2)] -> fragment order:
@@ -606,7 +389,6 @@ bool band_plan(BandLayer &a, BandPlan &p)
     if (a.stride != 1 && a.stride != 2) return false;
     if (a.x2 && (a.Cin2 % 32 || a.Cin2 < 64 || a.Cin2 > 512 || (a.stride2 != 1 && a.stride2 != 2))) return false;
     if (!a.x2) a.Cin2 = 0;
-    if (a.N > kMaxImages) return false;
     a.H = (a.Hin - 1) / a.stride + 1;
     a.W = (a.Win - 1) / a.stride + 1;
     if (a.H <= 0 || a.W <= 0 || a.Win + 1 > 113) return false;
@@ -645,7 +427,15 @@ unsigned long long *g_band_stamps = nullptr;
 int g_band_launch = 0;
 #endif
 
-int fill_layer(const char *name, BandLayer &a, BandPlan &p, const OgBandLayerDesc &d)
+struct BandDesc {
+    const void *x, *w_packed;
+    const float *bias;
+    const void *skip, *x2;
+    void *out;
+    int N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2;
+};
+
+int fill_layer(const char *name, BandLayer &a, BandPlan &p, const BandDesc &d)
 {
     OG_REQUIRE(d.x && d.w_packed && d.bias && d.out, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(d.N > 0 && d.Hin > 0 && d.Win > 0, OG_EINVAL, "%s: bad shape", name);
@@ -655,7 +445,7 @@ int fill_layer(const char *name, BandLayer &a, BandPlan &p, const OgBandLayerDes
     a.N = d.N; a.Hin = d.Hin; a.Win = d.Win; a.Cin = d.Cin; a.Cout = d.Cout; a.stride = d.stride; a.relu = d.relu;
     a.H2 = d.H2; a.W2 = d.W2; a.Cin2 = d.x2 ? d.Cin2 : 0; a.stride2 = d.stride2;
     OG_REQUIRE(band_plan(a, p), OG_EUNSUPPORTED,
-               "%s: not served (needs 64 <= Cin <= 512 in multiples of 32, Cout %% 16 == 0, stride 1|2, input width <= 112, batch <= 64, the "
+               "%s: not served (needs 64 <= Cin <= 512 in multiples of 32, Cout %% 16 == 0, stride 1|2, input width <= 112, the "
                "band in 160 KiB of LDS; got %dx%d, %d -> %d, stride %d, projection %d)", name, d.Hin, d.Win, d.Cin, d.Cout, d.stride, a.Cin2);
     return OG_OK;
 }
@@ -664,8 +454,7 @@ int fill_layer(const char *name, BandLayer &a, BandPlan &p, const OgBandLayerDes
 
 #ifndef OG_DT_F16
 #ifdef OG_BAND_STAMPS
-// buf: [launches][4096 workgroups][8] u64; every og_conv_band_* call after this fills the next [4096][8] block (a chained
-// launch: one block per layer, role (xcd, ticket) at xcd * 512 + ticket)
+// buf: [launches][4096 workgroups][8] u64; every og_conv_band_* call after this fills the next [4096][8] block
 OG_API void og_conv_band_debug_stamps(void *buf) { g_band_stamps = (unsigned long long *)buf; g_band_launch = 0; }
 #endif
 
@@ -678,11 +467,6 @@ OG_API int og_conv_band_supported(int N, int Hin, int Win, int Cin, int Cout, in
     if (Cin2 > 0) { a.x2 = (const unsigned short *)16; a.H2 = H2; a.W2 = W2; a.Cin2 = Cin2; a.stride2 = stride2; }
     if (!band_plan(a, p)) return 0;
     return a.total;
-}
-
-OG_API size_t og_conv_band_chain_workspace_bytes(void)
-{
-    return (size_t)(kMaxLayers * 8 + kMaxLayers * kMaxImages + 2) * kSyncStride * sizeof(int);
 }
 
 OG_API int og_conv_band_pack_w16(const void *w, const void *w2, int Cin, int Cout, int Cin2, void *packed, void *stream)
@@ -714,7 +498,7 @@ OG_API int OG_LP_NAME(og_conv_band)(const void *x, const void *w_packed, const f
                                     int stride2, void *stream)
 {
     const char *name = OG_LP_STR("og_conv_band");
-    const OgBandLayerDesc d = {x, w_packed, bias, skip, x2, out, N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2};
+    const BandDesc d = {x, w_packed, bias, skip, x2, out, N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2};
     BandLayer a;
     BandPlan p;
     const int rc = fill_layer(name, a, p, d);
@@ -734,94 +518,6 @@ OG_API int OG_LP_NAME(og_conv_band)(const void *x, const void *w_packed, const f
     } while (0)
     BAND_DISPATCH(BAND_LAUNCH, p.pt, a.kw, a.kw2);
 #undef BAND_LAUNCH
-    OG_LAUNCH_CHECK(name);
-    return OG_OK;
-}
-
-namespace {
-// Plans a chained launch: fills `args` (layers, LDS layout), -> status; pt / kw / kw2 / lds / grid describe the launch.
-int chain_plan(const char *name, const OgBandLayerDesc *layers, int n_layers, ChainArgs &args, int &pt, int &kw, int &kw2, int &lds, int &grid)
-{
-    OG_REQUIRE(layers, OG_EINVAL, "%s: null pointer", name);
-    OG_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers, OG_EUNSUPPORTED, "%s: 1 to %d layers per launch (got %d)", name, kMaxLayers, n_layers);
-    args = ChainArgs{};
-    pt = kw = kw2 = 0;
-    int max_total = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        BandPlan p;
-        const int rc = fill_layer(name, args.layer[l], p, layers[l]);
-        if (rc != OG_OK) return rc;
-        BandLayer &a = args.layer[l];
-        for (int e = 0; e < l; ++e) {
-            if (layers[l].x == layers[e].out) a.in_chain |= 1;
-            if (layers[l].skip && layers[l].skip == layers[e].out) a.in_chain |= 2;
-            if (layers[l].x2 && layers[l].x2 == layers[e].out) a.in_chain |= 4;
-            OG_REQUIRE(layers[l].out != layers[e].out, OG_EINVAL, "%s: layers %d and %d write the same buffer", name, e, l);
-        }
-        OG_REQUIRE(l == 0 || layers[l].x == layers[l - 1].out, OG_EUNSUPPORTED, "%s: layer %d must read layer %d's output", name, l, l - 1);
-        OG_REQUIRE(l == 0 || a.N == args.layer[0].N, OG_EINVAL, "%s: layers of one launch share the batch size", name);
-        pt = p.pt > pt ? p.pt : pt;
-        kw = a.kw > kw ? a.kw : kw;
-        kw2 = a.kw2 > kw2 ? a.kw2 : kw2;
-        max_total = a.total > max_total ? a.total : max_total;
-    }
-    // one column-block count for the launch: the layers that would choose a smaller one are laid out for it
-    lds = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const int need = band_lds(args.layer[l], pt);
-        lds = need > lds ? need : lds;
-    }
-    OG_REQUIRE(lds <= kMaxLds, OG_EUNSUPPORTED, "%s: the layers do not fit one LDS plan (%d bytes)", name, lds);
-    args.n_layers = n_layers;
-    args.word_off = (lds + 15) & ~15;
-    lds = args.word_off + 16;
-    // one workgroup per role of the widest layer, at most one per CU (every holder resident in the common case; with fewer
-    // resident workgroups each one only takes more roles)
-    grid = max_total < og_cu_count() ? max_total : og_cu_count();
-    grid = (grid + 7) / 8 * 8;
-    return OG_OK;
-}
-}  // namespace
-
-#ifndef OG_DT_F16
-// 1 when og_conv_band_chain_* serves the list as one launch (same checks, nothing runs), else 0 (og_last_error says why)
-OG_API int og_conv_band_chain_supported(const OgBandLayerDesc *layers, int n_layers)
-{
-    static thread_local ChainArgs args;
-    int pt, kw, kw2, lds, grid;
-    return chain_plan("og_conv_band_chain_supported", layers, n_layers, args, pt, kw, kw2, lds, grid) == OG_OK;
-}
-#endif
-
-// A chain of dependent layers in ONE launch: layer l reads what layer l-1 wrote (skip / x2 of a layer may be the `out` of any
-// EARLIER layer of the list, or tensors complete before the launch; the outputs must be distinct buffers).
-OG_API int OG_LP_NAME(og_conv_band_chain)(const OgBandLayerDesc *layers, int n_layers, void *workspace, size_t workspace_bytes, void *stream)
-{
-    const char *name = OG_LP_STR("og_conv_band_chain");
-    OG_REQUIRE(workspace, OG_EINVAL, "%s: null pointer", name);
-    OG_REQUIRE(workspace_bytes >= (size_t)(kMaxLayers * 8 + kMaxLayers * kMaxImages + 2) * kSyncStride * sizeof(int) &&
-                   (uintptr_t)workspace % 128 == 0,
-               OG_ENOSPC, "%s: workspace too small or not 128-byte aligned (og_conv_band_chain_workspace_bytes)", name);
-    static thread_local ChainArgs args;
-    int pt, kw, kw2, lds, grid;
-    const int rc = chain_plan(name, layers, n_layers, args, pt, kw, kw2, lds, grid);
-    if (rc != OG_OK) return rc;
-    args.sync = (int *)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned long long *stamps = nullptr;
-#ifdef OG_BAND_STAMPS
-    if (g_band_stamps) { stamps = g_band_stamps + (size_t)g_band_launch * 4096 * 8; g_band_launch += n_layers; }
-#endif
-#define CHAIN_LAUNCH(PT_, KW_, KW2_)                                                                                  \
-    do {                                                                                                              \
-        static OgAttrOnce attr_;                                                                                      \
-        if (attr_.need())                                                                                             \
-            (void)hipFuncSetAttribute((const void *)conv_band_chain_kernel<PT_, KW_, KW2_>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds + 32);                      \
-        hipLaunchKernelGGL((conv_band_chain_kernel<PT_, KW_, KW2_>), dim3((unsigned)grid), dim3(2 * 64 * kWaves), lds, st, args, stamps); \
-    } while (0)
-    BAND_DISPATCH(CHAIN_LAUNCH, pt, kw, kw2);
-#undef CHAIN_LAUNCH
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }

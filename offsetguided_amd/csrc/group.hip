@@ -1,5 +1,5 @@
 // K3 -- GreedyGroup.group_skeletons (decoder/group.py:39-185; _delete_reconns :221-240;
-// _delete_sort :187-219), device resident: one 4-wave workgroup per image.
+// _delete_sort :187-219), device resident: one 16-wave workgroup (1 024 threads) per image.
 //
 // The reference ships the limbs to the host (.cpu().numpy(), decoder/factory.py:91) and runs
 // numpy in a multiprocessing.Pool; here the partial-skeleton ("subset") table lives in LDS
@@ -7,7 +7,7 @@
 // data).  Everything that does not depend on the table -- validity filter, stable rank sort and
 // to-index de-duplication of the K candidates of EVERY limb type -- is done up front in parallel;
 // the limb types are then processed serially (that dependence is inherent), each step spread over
-// 256 lanes:
+// the workgroup's 1 024 lanes:
 //   * matching: lanes = (subset row, limb column) cells; per-row results by LDS atomicMax
 //     (phase B keeps the LAST matching column: numpy last-write-wins), per-column match counts
 //     by LDS atomicAdd;
@@ -32,6 +32,9 @@
 //            divide), fp64 threshold, stable descending order, -1 -> 0.
 // If more than mmax rows are ever created the image is flagged in status[] (caller retries
 // with a larger mmax; the table then lives in the caller's global workspace instead of LDS).
+// Capacity: the staged candidate rows (11 floats each) move to the global workspace as well when L*k
+// does not leave room for them in LDS (GLIM; e.g. omp44 at --topk 64); what must stay in LDS is
+// 16 B per candidate + 108 B per table row: L*k up to ~6 000 at mmax 128, any skeleton the reference defines at k <= 128.
 #include <math.h>
 
 #include <type_traits>
@@ -66,6 +69,7 @@ struct GroupArgs {
     float *poses;
     int32_t *counts, *status;
     float *gsub;  // global subset tables (N x mmax x nkp x 6) or nullptr -> LDS
+    float *glim;  // global staged candidate rows (N x L x K x 11) or nullptr -> LDS
 };
 
 __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairwise add.reduce, n <= 17
@@ -98,7 +102,7 @@ __device__ __forceinline__ float np_sum17(const float *v, int n)  // numpy pairw
 // 5 barriers per limb type (3 when the table is still empty).
 constexpr int kIdPitch = 20;
 
-template <bool GSUB>
+template <bool GSUB, bool GLIM>
 __global__ void __launch_bounds__(kThreads)
 greedy_group_kernel(GroupArgs A)
 {
@@ -117,10 +121,11 @@ greedy_group_kernel(GroupArgs A)
     float *p = reinterpret_cast<float *>(r_score + mmax);
     const bool wide_ok = (K & 3) == 0 && (mmax & 1) == 0;  // t_score/t_i2/t_dup rows on 16-byte boundaries
     const int LK4 = (LK + 3) & ~3;                         // array lengths rounded to 16 bytes: t_score .. t_dup are read wide
-    float *lim_all = p;          p += (size_t)((LK * 11 + 3) & ~3);  // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
+    float *lim_lds = p;          p += GLIM ? 0 : (size_t)((LK * 11 + 3) & ~3);  // per limb type: unique rows x1,y1,v1,s1,x2,y2,v2,s2,score,i1,i2
+    float *lim_glb = A.glim + (size_t)img * LK * 11;
+#define lim_all (GLIM ? lim_glb : lim_lds)
     float *t_score = p;          p += LK4;                 // up-front pass: score of valid candidates (-inf otherwise)
     int *t_i2 = (int *)p;        p += LK4;                 //                to-index
-    int *t_rank = (int *)p;      p += LK4;                 //                rank among the valid ones (stable, descending)
     int *t_dup = (int *)p;       p += LK4;                 //                a better-ranked row has the same to-index
     int *t_urank = (int *)p;     p += LK;                  //                rank among the valid, non-duplicate ones
     int *kk_arr = (int *)p;      p += L;                   // unique rows per limb type
@@ -150,7 +155,7 @@ greedy_group_kernel(GroupArgs A)
         const bool valid = c[8] < lim && c[0] > 0.f && c[4] > 0.f && c[3] > 0.f && c[1] > 0.f;
         t_score[i] = valid ? c[10] : -INFINITY;
         t_i2[i] = (int)c[7];
-        t_rank[i] = 0; t_dup[i] = 0; t_urank[i] = 0;
+        t_dup[i] = 0; t_urank[i] = 0;
     }
     for (int i = tid; i < L; i += kThreads) kk_arr[i] = 0;
     for (int i = tid; i < 2 * K; i += kThreads) { c_n1_2[i] = 0; c_n2_2[i] = 0; }
@@ -209,7 +214,6 @@ greedy_group_kernel(GroupArgs A)
                 rank += better;
                 dup |= better & (int)(t_i2[base + j] == my_i2);
             }
-            t_rank[lk] = rank;
             t_dup[lk] = dup;
         }
     };
@@ -483,23 +487,26 @@ greedy_group_kernel(GroupArgs A)
 #undef SUBP
 #undef LIM
 #undef sub
+#undef lim_all
 }
 
 constexpr size_t kLdsLimit = 159 * 1024;  // 160 KiB per CU minus the static __shared__ words
 
-size_t staging_bytes(int L, int K, int mmax)
+size_t staging_bytes(int L, int K, int mmax, bool glim)   // mirrors the kernel's carve-up
 {
-    const size_t lk = (size_t)L * K;
+    const size_t lk = (size_t)L * K, lk4 = (lk + 3) & ~(size_t)3;
     return (size_t)mmax * kIdPitch * 4 + (size_t)mmax * 8 +
-           (lk * 11 + lk * 5 + L + (size_t)K * 5 + (size_t)mmax * 5 + kScoreThreads * 17) * 4 + 64 + 6 * 16;
+           ((glim ? 0 : ((lk * 11 + 3) & ~(size_t)3)) + 3 * lk4 + lk + L + (size_t)K * 5 + (size_t)mmax * 5 + kScoreThreads * 17) * 4 + 64;
 }
+
+size_t table_ws_bytes(int N, int n_kp, int mmax) { return og_align_up((size_t)N * mmax * n_kp * 6 * sizeof(float), 256); }
 
 }  // namespace
 
-OG_API size_t og_group_workspace_bytes(int N, int n_kp, int mmax)
+OG_API size_t og_group_workspace_bytes(int N, int L, int k, int n_kp, int mmax)
 {
-    if (N <= 0 || n_kp <= 0 || mmax <= 0) return 0;
-    return og_align_up((size_t)N * mmax * n_kp * 6 * sizeof(float), 256);
+    if (N <= 0 || L <= 0 || k <= 0 || n_kp <= 0 || mmax <= 0) return 0;
+    return table_ws_bytes(N, n_kp, mmax) + og_align_up((size_t)N * L * k * 11 * sizeof(float), 256);
 }
 
 OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const int32_t *jf, const int32_t *jt,
@@ -516,20 +523,25 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
     GroupArgs a;
     a.limbs = limbs; a.jf = jf; a.jt = jt; a.L = L; a.K = k; a.nkp = n_kp; a.use_scale = use_scale;
     a.sort_dim = sort_dim; a.mmax = mmax; a.person_thre = person_thre; a.dist_max = dist_max;
-    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr;
-    size_t lds = staging_bytes(L, k, mmax);
-    OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: L*k=%d candidates (and mmax=%d) do not fit in LDS", name, L * k, mmax);
+    a.poses = poses; a.counts = counts; a.status = status; a.gsub = nullptr; a.glim = nullptr;
+    // What lives where: everything in LDS when it fits (the published configuration: 121 KB); else the table moves to the
+    // global workspace (GSUB), then the staged candidate rows as well (GLIM).
     const size_t table = (size_t)mmax * n_kp * 6 * sizeof(float);
-    if (lds + table <= kLdsLimit) {
-        lds += table;
-    } else {
-        OG_REQUIRE(workspace && workspace_bytes >= og_group_workspace_bytes(N, n_kp, mmax), OG_ENOSPC,
-                   "%s: mmax=%d needs a %zu-byte workspace", name, mmax, og_group_workspace_bytes(N, n_kp, mmax));
+    bool gsub = false, glim = false;
+    size_t lds = staging_bytes(L, k, mmax, false) + table;
+    if (lds > kLdsLimit) { gsub = true; lds -= table; }
+    if (lds > kLdsLimit) { glim = true; lds = staging_bytes(L, k, mmax, true); }
+    OG_REQUIRE(lds <= kLdsLimit, OG_EUNSUPPORTED, "%s: L*k=%d candidates and mmax=%d need %zu bytes of LDS (limit %zu)", name,
+               L * k, mmax, lds, kLdsLimit);
+    if (gsub) {
+        OG_REQUIRE(workspace && workspace_bytes >= og_group_workspace_bytes(N, L, k, n_kp, mmax), OG_ENOSPC,
+                   "%s: L=%d k=%d mmax=%d needs a %zu-byte workspace", name, L, k, mmax, og_group_workspace_bytes(N, L, k, n_kp, mmax));
         a.gsub = (float *)workspace;
+        if (glim) a.glim = (float *)((char *)workspace + table_ws_bytes(N, n_kp, mmax));
     }
-    void (*kern)(GroupArgs) = a.gsub ? greedy_group_kernel<true> : greedy_group_kernel<false>;
-    static OgAttrOnce attr_set[2];
-    if (attr_set[a.gsub ? 1 : 0].need()) {
+    void (*kern)(GroupArgs) = glim ? greedy_group_kernel<true, true> : gsub ? greedy_group_kernel<true, false> : greedy_group_kernel<false, false>;
+    static OgAttrOnce attr_set[3];
+    if (attr_set[glim ? 2 : gsub ? 1 : 0].need()) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         OG_REQUIRE(e == hipSuccess, OG_EHIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
     }

@@ -889,19 +889,9 @@ bool make_plan(long planes, int H, int W, int k, bool aligned16, Plan *p)
     rows = min(rows, H);
     p->rows = rows;
     p->nbands = (H + rows - 1) / rows;
-    // Work items: equal bands of OG_NMS_ROWS rows, or (OG_K1_BAND_WGS_PER_CU: n > 0 = n workgroups per CU, -1 = the multiple of
-    // the CU count nearest to planes x nbands) a balanced map when that keeps the bands within a quarter of the tuned height.
-    // Stand-alone on HBM-cold data the balanced map is 1 us faster (no fifth workgroup on every fourth CU); in the decode
-    // pipeline, where the batch has just been written, equal bands measured 0-2 us faster: the default.
-    static const int per_cu_env = env_int("OG_K1_BAND_WGS_PER_CU", 0);
+    // Work items: equal bands of OG_NMS_ROWS rows.  (A balanced map -- exactly n workgroups per CU, bands of 85 / 86 rows -- was 1 us
+    // faster stand-alone on HBM-cold data and 0-2 us slower in the decode pipeline: EXPERIMENTS.md; BandMap still describes both.)
     p->bm = BandMap{(int)planes, p->nbands, 0};
-    if (per_cu_env != 0 && planes < (1l << 12) && H < (1 << 20)) {   // (planes x work items and bands x H stay below 2^32)
-        const long cus = device_cu_count(), uniform = planes * p->nbands;
-        const long per_cu = per_cu_env > 0 ? per_cu_env : (uniform + cus / 2) / cus;
-        const long T = per_cu * cus;
-        if (T >= planes && T < (1l << 19) && T / planes + 1 <= 64 && H / (T / planes + 1) >= 16 && 4 * labs(T - uniform) <= uniform)
-            p->bm = BandMap{(int)planes, (int)(T / planes), (int)(T % planes)};
-    }
     p->max_bands = p->bm.b_lo + (p->bm.n_hi > 0 ? 1 : 0);
     p->total = bm_start(p->bm, (int)planes);
     p->cap = (2 * k + 64 + 63) / 64 * 64;

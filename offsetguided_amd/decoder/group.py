@@ -65,7 +65,7 @@ class GreedyGroup(object):
         jt = _lib.int_table([b for _, b in self.skeleton], dev)
         poses = torch.empty((n, mmax, self.n_keypoints, 6), dtype=torch.float32, device=dev)
         meta = torch.empty(2 * n, dtype=torch.int32, device=dev)
-        nbytes = lib.og_group_workspace_bytes(n, self.n_keypoints, mmax)
+        nbytes = lib.og_group_workspace_bytes(n, n_limbs, k, self.n_keypoints, mmax)
         ws = _lib.workspace(dev, nbytes, 'group')
         with _lib.stage_timer('k3_group', dev):
             _lib.check(lib.og_greedy_group_f32(

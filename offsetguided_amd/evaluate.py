@@ -1,7 +1,7 @@
 """Inference harness with the reference evaluate.py surface (evaluate_cli :49-122, run_images
 :125-300, validation :303-328), MI355X-native underneath:
 
-  images -> models.InferenceEngine (bf16 NHWC, HIP graph) -> decoder.PostProcess.submit (HIP kernels,
+  images -> models.InferenceEngine (fp16 NHWC: the reference's apex-O2 arithmetic, HIP graph) -> decoder.PostProcess.submit (HIP kernels,
   batch i+1's backbone is queued before batch i's poses are collected) -> annotations_inverse ->
   COCO-style result dicts.
 
@@ -109,6 +109,9 @@ def synthetic_loader(n_batches, batch_size, size, device, seed=0):
         yield images, [None] * batch_size, metas
 
 
+ENGINE_CACHE = 4     # engines (input shapes) run_images keeps alive
+
+
 def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
     """The hot loop of evaluate.py:207-298.  Returns (result_keypoints, result_image_ids)."""
     if not torch.cuda.is_available():
@@ -124,7 +127,11 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
     if data_loader is None:
         data_loader = synthetic_loader(n_synthetic_batches, args.batch_size, args.long_edge, dev)
     feeder = DeviceFeeder(dev)
-    engines = {}            # one engine (scratch + captured graph) per input shape; a ragged last batch is padded instead
+    # one engine (scratch + captured graph) per input shape, the ENGINE_CACHE most recently used ones kept (--fixed-height: one
+    # shape per width); the folded / tiled weights are shared between them (models/engine.py:_shared_layers); a ragged last batch
+    # is padded instead of getting an engine of its own
+    import collections
+    engines = collections.OrderedDict()
     batch_time, end, last_print, pending = AverageMeter(), time.time(), -1, None
     full_batch = None
 
@@ -164,41 +171,51 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                 nxt = None
             yield cur
 
-    for batch_idx, ((images, _, metas), packed) in enumerate(ahead(data_loader)):
-        if packed is not None:
-            # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
-            # (RescaleLongAbsolute + CenterPad, or with --fixed-height RescaleHighAbsolute + RightDownPad of :150-156, then
-            # ToTensor + Normalize; pinned staging packed a batch ahead, one H2D copy); metas are derived here
-            images, metas = preprocess[0](images, image_ids=[m['image_id'] for m in metas], packed=packed.result())
-        images = feeder(images)
-        full_batch = full_batch or images.shape[0]
-        if images.shape[0] < full_batch:   # last batch of the dataset: fill up to the engine's batch, results are dropped
-            images = torch.cat((images, images[-1:].expand(full_batch - images.shape[0], -1, -1, -1)))
-        if args.flip_test:
-            images = torch.cat((images, torch.flip(images, [-1])))
-        engine = engines.get(tuple(images.shape))
-        if engine is None:
-            engine = engines[tuple(images.shape)] = models.InferenceEngine(
-                model, images.shape[0], images.shape[2], images.shape[3], device=dev, feat_stage=args.feat_stage)
-        outputs = engine(images)
-        handle = (processor.submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
+    try:
+        for batch_idx, ((images, _, metas), packed) in enumerate(ahead(data_loader)):
+            if packed is not None:
+                # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
+                # (RescaleLongAbsolute + CenterPad, or with --fixed-height RescaleHighAbsolute + RightDownPad of :150-156, then
+                # ToTensor + Normalize; pinned staging packed a batch ahead, one H2D copy); metas are derived here
+                images, metas = preprocess[0](images, image_ids=[m['image_id'] for m in metas], packed=packed.result())
+            images = feeder(images)
+            full_batch = full_batch or images.shape[0]
+            if images.shape[0] < full_batch:   # last batch of the dataset: fill up to the engine's batch, results are dropped
+                images = torch.cat((images, images[-1:].expand(full_batch - images.shape[0], -1, -1, -1)))
+            if args.flip_test:
+                images = torch.cat((images, torch.flip(images, [-1])))
+            engine = engines.pop(tuple(images.shape), None)
+            if engine is None:
+                if len(engines) >= ENGINE_CACHE:
+                    if pending is not None:      # the batch in flight still reads the outputs of the engine that goes
+                        collect(pending)
+                        pending = None
+                    engines.popitem(last=False)
+                engine = models.InferenceEngine(model, images.shape[0], images.shape[2], images.shape[3], device=dev,
+                                                feat_stage=args.feat_stage)
+            engines[tuple(images.shape)] = engine            # most recently used last
+            outputs = engine(images)
+            handle = (processor.submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
+            if pending is not None:
+                collect(pending)
+            pending = handle
+            if batch_idx % args.print_freq == 0:
+                torch.cuda.synchronize()
+                now = time.time()
+                per_batch = (now - end) / (batch_idx - last_print)   # batches since the last print (1 at the first), not print_freq
+                end, last_print = now, batch_idx
+                if batch_idx > 0:                                    # the first batch builds the engine: not a speed sample
+                    batch_time.update(per_batch)
+                print('==================> [{0}]\tTime {1:.3f} ({2:.3f})\tSpeed {3:.3f} ({4:.3f})'.format(
+                    batch_idx, per_batch, batch_time.avg or per_batch, args.batch_size / per_batch,
+                    args.batch_size / (batch_time.avg or per_batch)))
         if pending is not None:
             collect(pending)
-        pending = handle
-        if batch_idx % args.print_freq == 0:
-            torch.cuda.synchronize()
-            now = time.time()
-            per_batch = (now - end) / (batch_idx - last_print)   # batches since the last print (1 at the first), not print_freq
-            end, last_print = now, batch_idx
-            if batch_idx > 0:                                    # the first batch builds the engine: not a speed sample
-                batch_time.update(per_batch)
-            print('==================> [{0}]\tTime {1:.3f} ({2:.3f})\tSpeed {3:.3f} ({4:.3f})'.format(
-                batch_idx, per_batch, batch_time.avg or per_batch, args.batch_size / per_batch,
-                args.batch_size / (batch_time.avg or per_batch)))
-    if pending is not None:
-        collect(pending)
-    if packer[0] is not None:
-        packer[0].shutdown()
+    finally:
+        # also on an exception (engine build failure, OgError, the --fixed-height assertion): the worker must not outlive the
+        # call holding pinned staging buffers, and a pack still queued must not write one while the caller handles the error
+        if packer[0] is not None:
+            packer[0].shutdown(wait=True, cancel_futures=True)
     return result_keypoints, result_image_ids
 
 

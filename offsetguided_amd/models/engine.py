@@ -24,10 +24,8 @@ train / eval flag and device stay as they are.
 Environment switches (read at import; the measured-best value is the default): OG_CONV_TILED (7: bit 0 / 1 / 2 = 3x3 stride 1 /
 3x3 stride 2 / 1x1 layers on the tiled kernels), OG_CONV_UP2 (1: merges on the producing convolution's epilogue),
 OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (1: capture order at the forks of
-depth >= 1), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024) /
-OG_CONV_BAND_CHAIN (0): the band-resident kernel for 10x10 / 5x5, OG_CONV_TILED_CHAIN (dependent 160x160 layers as one launch),
-OG_ENGINE_WHATIF (timing diagnosis,
-wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
+depth >= 1), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024: the
+band-resident kernel for 10x10 / 5x5), OG_ENGINE_WHATIF (timing diagnosis, wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
 EXPERIMENTS.md and no longer exist as switches.
 """
 import os
@@ -86,18 +84,10 @@ CONV_TILED_MIN_PIXELS = 2048     # 20x20 at batch 8 = 3 200 pixels: 20 x 4 tiles
 # OG_CONV_BAND_MAX_PIXELS = P (default 1024; 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with
 # at most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: one 4-wave workgroup per (image,
 # row band, 16 output channels), K split over its waves, partial tiles summed in LDS -- no fp32 slabs, no tickets) where it serves
-# the shape: 1024 = the 10x10 / 5x5 levels at batch 8.  With OG_CONV_BAND_CHAIN=1 (default 0) runs of such residual blocks go out
-# as ONE chained persistent launch (og_conv_band_chain_*).  Measured (round 4, EXPERIMENTS.md): a 5x5 layer alone 12.4 -> 8.2 us
-# (7.4 chained), a 10x10 layer 13.7 -> 11.7; in the network the 4-wave kernel is worth 1.3 % of the step TOGETHER with
-# OG_ENGINE_DEEP_SHARED=3 (each alone: nothing), the chained launch costs 1-4 % (it holds all 256 CUs for its ~100 us, the up1
-# branches that run beside the bottom of the hourglass wait for it instead of sharing the chip).
+# the shape: 1024 = the 10x10 / 5x5 levels at batch 8.  Measured (round 4, EXPERIMENTS.md): a 5x5 layer alone 12.4 -> 8.2 us, a
+# 10x10 layer 13.7 -> 11.7; in the network the kernel is worth 1.3 % of the step TOGETHER with OG_ENGINE_DEEP_SHARED=3 (each alone:
+# nothing).  (Chained persistent launches of these layers / of the 160x160 layers: tools/experiments/*_chain.patch.)
 CONV_BAND_MAX_PIXELS = int(os.environ.get('OG_CONV_BAND_MAX_PIXELS', '1024'))
-CONV_BAND_CHAIN = int(os.environ.get('OG_CONV_BAND_CHAIN', '0'))
-# OG_CONV_TILED_CHAIN = W (0 = off): runs of up to four DEPENDENT 3x3 stride-1 layers of the tiled kernel (two residual blocks) whose
-# launches have at least W workgroups each go out as ONE chained launch (og_conv3x3_tiled_chain_*): the next layer's workgroups wait
-# tile by tile for the tiles under their halo and fill the partly filled last round of the layer before instead of idling to the
-# kernel boundary.  Pays where a layer has more workgroups than the chip has slots (512): the 160x160 layers at batch 8 (1 600).
-CONV_TILED_CHAIN = int(os.environ.get('OG_CONV_TILED_CHAIN', '0'))
 # The up1 branch of every hourglass level is independent of the whole pyramid below it (kp_module.forward,
 # models/hourglass_104.py:183-190).  With OG_ENGINE_BRANCHES=1 it runs on its own stream, forked and joined inside the
 # captured HIP graph, so that the large up1 convolutions fill the CUs the latency-bound 20x20..5x5 levels leave idle.
@@ -116,7 +106,6 @@ TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
 # and the trunk waits for it at the depth-3 merge.  A/B over three runs: 6.02 -> 5.95 ms with the band kernel, D = 2 / 4 lose.
 DEEP_SHARED = int(os.environ.get('OG_ENGINE_DEEP_SHARED', '3'))
 CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
-_chain_ws = {}
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
 class _Issuer(threading.local):
@@ -227,28 +216,19 @@ class _Conv:
 
     def band_pack(self, device, proj=None):
         """The layer's weights (+ the projection's) in og_conv_band_*'s fragment order, packed once (never inside graph capture)."""
+        c2 = proj.w.shape[1] if proj is not None else 0
+        # the packed image holds the projection's weights behind the 3x3 ones: a layer is packed for ONE of the two routes
+        assert self.w_band is None or self.w_band_c2 == c2, 'band_pack: layer already packed with a different projection'
         if self.w_band is None:
             assert not torch.cuda.is_current_stream_capturing(), 'weights must be packed before graph capture'
             lib = _lib.load()
             cout, c = self.w.shape[0], self.w.shape[1]
-            c2 = proj.w.shape[1] if proj is not None else 0
+            self.w_band_c2 = c2
             self.w_band = torch.empty(cout * (9 * c + c2), dtype=self.w.dtype, device=self.w.device)
             w2 = proj.w.reshape(cout, c2).contiguous() if proj is not None else None
             _lib.check(lib.og_conv_band_pack_w16(_lib.ptr(self.w), _lib.ptr(w2) if w2 is not None else None, c, cout, c2,
                                                  _lib.ptr(self.w_band), _lib.stream_ptr(device)), lib)
         return self.w_band
-
-    def band_desc(self, x, out, skip=None, x2=None, proj=None):
-        """This layer as one entry of an og_conv_band_chain_* launch (tensors channels-last)."""
-        n, c, h, w = x.shape
-        h2 = w2 = c2 = 0
-        st2 = 1
-        if proj is not None:
-            _, c2, h2, w2 = x2.shape
-            st2 = proj.stride[0]
-        return _lib.BandLayerDesc(_lib.ptr(x), _lib.ptr(self.band_pack(x.device, proj)), _lib.ptr(self.b32),
-                                  _lib.ptr(skip) if skip is not None else None, _lib.ptr(x2) if proj is not None else None,
-                                  _lib.ptr(out), n, h, w, c, self.w.shape[0], self.stride[0], int(self.relu), h2, w2, c2, st2)
 
     def band(self, x, skip=None, x2=None, proj=None):
         """act(conv3x3(x) (+ conv1x1(x2) of `proj`) + bias (+ skip)) on og_conv_band_* (bias = the sum of both folded biases when a
@@ -445,140 +425,11 @@ def _seq(mods, dtype, fused):
     return [_Residual(m, dtype, fused) for m in mods]
 
 
-def _chain_workspace(device):
-    """The zero-initialised words of og_conv_band_chain_* launches, one set per (device, engine, concurrent branch): launches
-    of one branch are stream-ordered, and every launch leaves its words zero."""
-    key = (device.index, _issuer.engine, _issuer.branch)
-    buf = _chain_ws.get(key)
-    if buf is None:
-        assert not torch.cuda.is_current_stream_capturing(), 'the chain workspace must exist before graph capture'
-        buf = _chain_ws[key] = torch.zeros(int(_lib.load().og_conv_band_chain_workspace_bytes()), dtype=torch.uint8, device=device)
-    return buf
-
-
-def _tiled_chain_workspace(device):
-    key = ('tiled', device.index, _issuer.engine, _issuer.branch)
-    buf = _chain_ws.get(key)
-    if buf is None:
-        assert not torch.cuda.is_current_stream_capturing(), 'the chain workspace must exist before graph capture'
-        buf = _chain_ws[key] = torch.zeros(int(_lib.load().og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=device)
-    return buf
-
-
-def _tiled_chain_from(blocks, i, x, after_first=None):
-    """Residual blocks i, i + 1 (both convolutions of each on the tiled stride-1 kernel, no projection) as ONE chained launch of
-    two to four layers: -> (output, index of the first block not consumed) or None."""
-    if not (CONV_TILED_CHAIN and (CONV_TILED & 1) and x.is_cuda) or _WHATIF:
-        return None
-    cl = torch.channels_last
-    lib = _lib.load()
-    descs, cur, j = [], x, i
-    n, _, h, w = x.shape
-    while j < len(blocks) and len(descs) + 2 <= 4:
-        r = blocks[j]
-        if not (isinstance(r, _Residual) and r.skip is None and r.c1.hip3x3 and r.c2.hip3x3
-                and tuple(r.c1.stride) == (1, 1) and tuple(r.c2.stride) == (1, 1) and r.c1.w.dtype == cur.dtype):
-            break
-        c, mid, cout = cur.shape[1], r.c1.w.shape[0], r.c2.w.shape[0]
-        ok = True
-        for ci, co in ((c, mid), (mid, cout)):
-            kind = lib.og_conv3x3_tiled_supported(n, h, w, ci, co)
-            tile = {1: 256, 2: 160}.get(kind)
-            ok = ok and tile is not None and n * h * w // tile * (co // 128) >= CONV_TILED_CHAIN
-        if not ok or cout != c:
-            break
-        if not cur.is_contiguous(memory_format=cl):
-            cur = cur.contiguous(memory_format=cl)
-        y = torch.empty((n, mid, h, w), dtype=cur.dtype, device=cur.device, memory_format=cl)
-        out = torch.empty((n, cout, h, w), dtype=cur.dtype, device=cur.device, memory_format=cl)
-        for conv, cin_ in ((r.c1, c), (r.c2, mid)):
-            if conv.w_tiled is None:
-                assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
-                conv.w_tiled = torch.empty(conv.w.numel(), dtype=conv.w.dtype, device=conv.w.device)
-                _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(conv.w), cin_, conv.w.shape[0], 0, _lib.ptr(conv.w_tiled), _lib.stream_ptr(cur.device)), lib)
-        descs.append((_lib.TiledLayerDesc(_lib.ptr(cur), _lib.ptr(r.c1.w_tiled), _lib.ptr(r.c1.b32), None, _lib.ptr(y), None,
-                                          n, h, w, c, mid, int(r.c1.relu)), (cur, y)))
-        descs.append((_lib.TiledLayerDesc(_lib.ptr(y), _lib.ptr(r.c2.w_tiled), _lib.ptr(r.c2.b32), _lib.ptr(cur), _lib.ptr(out), None,
-                                          n, h, w, mid, cout, int(r.c2.relu)), (y, out)))
-        cur, j = out, j + 1
-    if len(descs) < 2 or not _lib.tiled_chain_supported([d for d, _ in descs]):
-        return None
-    _lib.tiled_chain([d for d, _ in descs], cur.dtype, _tiled_chain_workspace(cur.device), cur.device)
-    if after_first is not None:
-        after_first()
-    return cur, j
-
-
-def _chain_from(blocks, i, x, after_first=None):
-    """The longest run of convolutions starting at residual block i that og_conv_band_chain_* serves as ONE launch (stride-1 3x3
-    layers on the band kernel's smallest tile, <= 16 layers): -> (output, index of the first block not consumed) or None.
-    A block whose conv1 has stride 2 may open a run with its conv2 (+ projection)."""
-    if not (CONV_BAND_CHAIN and CONV_BAND_MAX_PIXELS and x.is_cuda) or _WHATIF:
-        return None
-    cl = torch.channels_last
-    descs, keep, cur, j, opened_s2 = [], [], x, i, None
-    while j < len(blocks) and len(descs) + 2 <= 16:
-        r = blocks[j]
-        if not isinstance(r, _Residual):
-            break
-        c1s1 = tuple(r.c1.stride) == (1, 1)
-        n, _, h, w = cur.shape
-        st = r.c1.stride[0]
-        y_shape = (n, r.c1.w.shape[0], (h - 1) // st + 1, (w - 1) // st + 1)
-        if not r.c1.band_ok(cur) or (not c1s1 and descs):
-            break
-        proj = r.skip
-        if not r.c2.band_ok_shape(y_shape, cur.shape if proj is not None else None, proj, cur.dtype):
-            break
-        if not cur.is_contiguous(memory_format=cl):
-            cur = cur.contiguous(memory_format=cl)
-        y = torch.empty(y_shape, dtype=cur.dtype, device=cur.device, memory_format=cl)
-        if c1s1:
-            descs.append(r.c1.band_desc(cur, y))
-        else:
-            # stride 2: its own launch (into y); the run opens with conv2.  Only where the next block can follow.
-            nxt = blocks[j + 1] if j + 1 < len(blocks) else None
-            if not (isinstance(nxt, _Residual) and tuple(nxt.c1.stride) == (1, 1)
-                    and nxt.c1.band_ok_shape((n, r.c2.w.shape[0]) + tuple(y_shape[2:]), None, None, cur.dtype)):
-                break
-            opened_s2 = (r.c1, cur, y)
-        out = torch.empty((n, r.c2.w.shape[0]) + tuple(y_shape[2:]), dtype=cur.dtype, device=cur.device, memory_format=cl)
-        descs.append(r.c2.band_desc(y, out, skip=cur if proj is None else None, x2=cur if proj is not None else None, proj=proj))
-        keep += [cur, y, out]
-        cur, j = out, j + 1
-    # the library plans the list exactly as the launch will (one tile size, one LDS layout): shorten the run until it fits
-    while len(descs) >= 2 and not _lib.band_chain_supported(descs):
-        descs, j = descs[:-2], j - 1
-        cur = keep[3 * (j - i) - 1] if j > i else x
-    if len(descs) < 2:
-        return None
-    if opened_s2:
-        c1, xin, y = opened_s2
-        lib = _lib.load()
-        nn, cc, hh, ww = xin.shape
-        _lib.check(_lib.lp(lib, 'og_conv_band', xin.dtype)(
-            _lib.ptr(xin), _lib.ptr(c1.band_pack(xin.device)), _lib.ptr(c1.b32), None, None, _lib.ptr(y), nn, hh, ww, cc, c1.w.shape[0],
-            c1.stride[0], int(c1.relu), 0, 0, 0, 1, _lib.stream_ptr(xin.device)), lib)
-        if after_first is not None:
-            after_first()
-            after_first = None
-    _lib.band_chain(descs, cur.dtype, _chain_workspace(cur.device), cur.device)
-    if after_first is not None:
-        after_first()
-    return cur, j
-
-
 def _run(seq, x, after_first=None):
-    """The blocks of `seq` in order; runs of small-level residuals go out as chained launches.  after_first: called once the
-    first kernel has been launched (fork point of a side branch, _Level)."""
-    i = 0
-    while i < len(seq):
-        run = _tiled_chain_from(seq, i, x, after_first if i == 0 else None) or _chain_from(seq, i, x, after_first if i == 0 else None)
-        if run is None:
-            x = seq[i](x, after_c1=after_first) if (i == 0 and after_first is not None) else seq[i](x)
-            i += 1
-        else:
-            x, i = run
+    """The blocks of `seq` in order.  after_first: called once the first kernel has been launched (fork point of a side branch,
+    _Level)."""
+    for i, blk in enumerate(seq):
+        x = blk(x, after_c1=after_first) if (i == 0 and after_first is not None) else blk(x)
     return x
 
 
@@ -591,7 +442,7 @@ class _Level:
 
     def _lower(self, x, after_first=None):
         """-> the input of low3's LAST residual (that one runs after the join: the merge may ride on its epilogue)"""
-        if not isinstance(self.low2, _Level):      # the bottom of the hourglass: one list, so that a chained launch can span it
+        if not isinstance(self.low2, _Level):      # the bottom of the hourglass
             return _run(self.low1 + self.low2 + self.low3[:-1], x, after_first)
         low = _run(self.low1, x, after_first)
         low = self.low2(low)
@@ -643,11 +494,7 @@ class _Level:
         else:
             low = self._lower(x)
             up = _run(self.up1, x)
-        run = _chain_from(self.low3[-1:], 0, low) if self.fused else None     # small levels: the block's two convolutions as one launch
-        if run is not None:
-            low = run[0]
-        else:
-            low = self.low3[-1](low, merge_up=up if self.fused and up.is_contiguous(memory_format=torch.channels_last) else None)
+        low = self.low3[-1](low, merge_up=up if self.fused and up.is_contiguous(memory_format=torch.channels_last) else None)
         if low is None:
             return up   # up += nearest_x2(low3(low)) happened in the last convolution's epilogue
         if self.fused:  # up += nearest_x2(low) in one pass
@@ -659,31 +506,20 @@ class _Level:
         return up
 
 
-class InferenceEngine:
-    """engine = InferenceEngine(model, batch, H, W); feats = engine(images)  (images fp32 NCHW on device).
+class _Layers:
+    """The shape-independent part of an engine: every layer's folded weights (+ the tiled / packed images the kernels want, made
+    on first use) and the head tensors.  Shared by the engines of one (model state, dtype, device, decoded stage)."""
+    FIELDS = ('pre', 'kps', 'cnvs', 'inters', 'inters_', 'cnvs_', 'hm', 'off', 'scale', 'jitter', 'stem_w', 'heads_w', 'heads_b',
+              'head_channels')
 
-    `batch` is the number of images per call (2x the evaluation batch with flip-test).  dtype: torch.float16 (default: the
-    reference evaluates in fp16 through apex O2, evaluate.py:92,198-201), torch.bfloat16 (same kernels, same MFMA rate, 8x the
-    rounding error) or torch.float32 (plain torch ops: the checking path)."""
-
-    def __init__(self, model, batch, height, width, dtype=torch.float16, device='cuda:0', feat_stage=-1,
-                 use_graph=True):
-        assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
-        global _n_engines
-        self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
-        _n_engines += 1
-        self.device = torch.device(device)
-        self.dtype = dtype
-        self.shape = (batch, 3, height, width)
-        net = model.basenet
-        self.n_stacks = net.nstack
-        self.stage = feat_stage % self.n_stacks
-        # the caller's module is only read: weights are folded from it onto the engine's device (no .to(), no .eval())
-        _issuer.build_device = self.device
+    def __init__(self, model, dtype, device, stage, fused):
         dev_model = model
-        assert isinstance(net.pre[0], ConvBlock) and isinstance(net.pre[1], Residual)
-        # hand-written HIP kernels on the GPU 16-bit paths (bf16, or fp16 = the reference's apex-O2 arithmetic)
-        fused = self.fused = (self.device.type == 'cuda' and dtype in (torch.bfloat16, torch.float16))
+        self.heads_b, self.head_channels = None, None
+        net = model.basenet
+        self.stage = stage
+        # the caller's module is only read: weights are folded from it onto the engine's device (no .to(), no .eval())
+        _issuer.build_device = device
+        dev_model = model
         self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype, fused), _Residual(net.pre[1], dtype, fused)]
         self.kps = [_Level(net.kps[s], dtype, fused) for s in range(self.stage + 1)]
         self.cnvs = [_Conv(net.cnvs[s].conv, net.cnvs[s].bn, True, dtype, fused) for s in range(self.stage + 1)]
@@ -706,7 +542,7 @@ class InferenceEngine:
         self.stem_w = None
         c0 = net.pre[0].conv
         if (fused and tuple(c0.weight.shape) == (128, 3, 7, 7)
-                and tuple(c0.stride) == (2, 2) and tuple(c0.padding) == (3, 3) and height % 32 == 0 and width % 32 == 0):
+                and tuple(c0.stride) == (2, 2) and tuple(c0.padding) == (3, 3)):
             w7 = self.pre[0].w.float().permute(0, 2, 3, 1)                       # (128, ky, kx, ch), BN folded
             packed = torch.zeros((128, 7, 8, 4), dtype=torch.float32, device=w7.device)
             packed[:, :, :7, :3] = w7
@@ -726,6 +562,63 @@ class InferenceEngine:
             self.heads_w = w.contiguous(memory_format=torch.channels_last)
             self.heads_b = b.contiguous()
         _issuer.build_device = None
+
+
+_layer_cache = {}       # key -> (weak reference to the module, _Layers); at most _LAYER_CACHE_MAX entries, oldest dropped first
+_LAYER_CACHE_MAX = 2
+
+
+def _model_signature(model):
+    """Identity of a module's CURRENT weights: storage address, version counter, shape and sum of every parameter and buffer --
+    an optimizer step, load_state_dict, .to() or a write through .data changes it, so a cached bundle never serves stale weights
+    (0.2 s for Hourglass-104 on the host, a few ms on the device; an engine build takes seconds)."""
+    sig = 0
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            sig = hash((sig, t.data_ptr(), t._version, tuple(t.shape), float(t.double().sum()) if t.numel() else 0.0))
+    return sig
+
+
+def _shared_layers(model, dtype, device, stage, fused):
+    import weakref
+    key = (id(model), _model_signature(model), dtype, str(device), stage, fused)
+    hit = _layer_cache.pop(key, None)
+    if hit is not None and hit[0]() is not model:     # the id of a module that no longer exists
+        hit = None
+    if hit is None:
+        hit = (weakref.ref(model), _Layers(model, dtype, device, stage, fused))
+        while len(_layer_cache) >= _LAYER_CACHE_MAX:
+            _layer_cache.pop(next(iter(_layer_cache)))
+    _layer_cache[key] = hit      # (re-)inserted last: most recently used
+    return hit[1]
+
+
+class InferenceEngine:
+    """engine = InferenceEngine(model, batch, H, W); feats = engine(images)  (images fp32 NCHW on device).
+
+    `batch` is the number of images per call (2x the evaluation batch with flip-test).  dtype: torch.float16 (default: the
+    reference evaluates in fp16 through apex O2, evaluate.py:92,198-201), torch.bfloat16 (same kernels, same MFMA rate, 8x the
+    rounding error) or torch.float32 (plain torch ops: the checking path)."""
+
+    def __init__(self, model, batch, height, width, dtype=torch.float16, device='cuda:0', feat_stage=-1,
+                 use_graph=True):
+        assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
+        global _n_engines
+        self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
+        _n_engines += 1
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.shape = (batch, 3, height, width)
+        self.n_stacks = model.basenet.nstack
+        self.stage = feat_stage % self.n_stacks
+        assert isinstance(model.basenet.pre[0], ConvBlock) and isinstance(model.basenet.pre[1], Residual)
+        # hand-written HIP kernels on the GPU 16-bit paths (bf16, or fp16 = the reference's apex-O2 arithmetic)
+        self.fused = (self.device.type == 'cuda' and dtype in (torch.bfloat16, torch.float16))
+        # folded / tiled / packed weights do not depend on the input shape: engines of one (model state, dtype, device, stage)
+        # share them (evaluate.run_images builds one engine per input shape, --fixed-height: one per width)
+        self._layers = _shared_layers(model, dtype, self.device, self.stage, self.fused)
+        for name in _Layers.FIELDS:
+            setattr(self, name, getattr(self._layers, name))
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -765,7 +658,7 @@ class InferenceEngine:
                 and feat.is_contiguous(memory_format=torch.channels_last)):
             lib = _lib.load()
             n, c, h, w = feat.shape
-            if self.heads_tiled is None:
+            if self._layers.heads_tiled is None:
                 assert not torch.cuda.is_current_stream_capturing(), 'weights must be tiled before graph capture'
                 cout = (sum(self.head_channels) + 63) // 64 * 64
                 wpad = torch.zeros((cout, c), dtype=self.heads_w.dtype, device=self.heads_w.device)
@@ -774,8 +667,8 @@ class InferenceEngine:
                 bpad[:self.heads_b.shape[0]] = self.heads_b
                 packed = torch.empty(wpad.numel(), dtype=wpad.dtype, device=wpad.device)
                 _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wpad), c, cout, 3, _lib.ptr(packed), _lib.stream_ptr(feat.device)), lib)
-                self.heads_tiled = (packed, bpad, cout)
-            packed, bpad, cout = self.heads_tiled
+                self._layers.heads_tiled = (packed, bpad, cout)
+            packed, bpad, cout = self._layers.heads_tiled
             outs = [torch.empty((n, ch, h, w), dtype=torch.float32, device=feat.device) for ch in self.head_channels]
             import ctypes as C
             chans = (C.c_int * len(outs))(*self.head_channels)

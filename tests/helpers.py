@@ -12,6 +12,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FLAGS = dict(topk=32, thre_hmp=0.04, person_thre=0.04, dist_max=40.0, min_len=0.5)
 PIPE_CASES = ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe256_flip_p20",
               "pipe640", "pipe640_flip", "pipe256_flipcat_p6", "pipe640_flipcat"]
+# head configurations the drop-in surface accepts besides the default (decoder/factory.py:211-225), no flip / flip / cat_flip_offs
+# each; omp44 and omp19 also at the CLI's default --topk 48 (decoder/factory.py:154)
+SKELETON_CASES = [f"pipe256_{hn}{v}_p6" for hn in ("omp16", "omp31", "omp44", "omp25") for v in ("", "_flip", "_flipcat")] + \
+    ["pipe256_omp44_k48_p20", "pipe256_omp44_k48_flip_p20", "pipe640_omp31_k48_flip", "pipe256_omp19_k48_p6"]
+PIPE_CASES = PIPE_CASES + SKELETON_CASES
 EXACT_LIMB_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12]
 EXACT_POSE_COLS = [0, 1, 2, 3, 5]
 
@@ -23,6 +28,21 @@ def sha(a):
 def flip_tables(skeleton=COCO_PERSON_SKELETON):
     perm, rev = offset_hflip(COCO_KEYPOINTS, skeleton)
     return heatmap_hflip(COCO_KEYPOINTS), perm, rev
+
+
+def case_headnet(g):
+    """Name of the offset head of a pipeline fixture ('omp' for the fixtures that predate the field)."""
+    return str(g["headnet"]) if "headnet" in g.files else "omp"
+
+
+def case_skeleton(g):
+    from offsetguided_amd.decoder.factory import parse_heads
+    return parse_heads(case_headnet(g), 4)["skeleton"]
+
+
+def case_flags(g):
+    """FLAGS of a pipeline fixture (topk is a field of the newer ones)."""
+    return dict(FLAGS, topk=int(g["topk"])) if "topk" in g.files else dict(FLAGS)
 
 
 def is_cat(g):
@@ -66,7 +86,8 @@ def load_case(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     n_persons = int(g["n_persons"])
     hm, off = synth.synth_batch(int(g["seed"]), int(g["batch"]), int(g["size"]), int(g["size"]),
-                                flip=bool(g["flip"]), n_persons=None if n_persons < 0 else n_persons)
+                                flip=bool(g["flip"]), n_persons=None if n_persons < 0 else n_persons,
+                                skeleton=case_skeleton(g))
     assert [sha(hm), sha(off)] == list(g["in_sha"]), "synthetic input generator drifted (not a parity failure)"
     return g, hm, off
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     typed = _lib.load()
     assert typed.og_abi_version() == _lib.ABI_VERSION
     assert typed.og_topk_workspace_bytes(136, 640, 640, 32) > 0       # pure host arithmetic
-    assert typed.og_group_workspace_bytes(8, 17, 128) == 8 * 128 * 17 * 6 * 4
+    assert typed.og_group_workspace_bytes(8, 19, 32, 17, 128) == 8 * 128 * 17 * 6 * 4 + 8 * 19 * 32 * 11 * 4
 
 
 def test_argument_validation_without_gpu():

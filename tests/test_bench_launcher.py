@@ -61,9 +61,10 @@ def test_rank_pinning_picks_the_numa_node_of_the_gpu(monkeypatch):
     half = max(1, len(have) // 2)
     nodes = [(0, have[:half]), (1, have[half:] or have[:half])]
     monkeypatch.setattr(bench, 'numa_nodes', lambda: nodes)
+    monkeypatch.setattr(bench, 'gpu_numa_nodes', lambda: None)       # no topology in sysfs: the device-order rule
     pinned = []
     monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus: pinned.append(sorted(cpus)))
-    assert bench.pin_rank(0, 8) == {'node': 0, 'cpus': len(nodes[0][1])} and pinned[-1] == sorted(nodes[0][1])
+    assert bench.pin_rank(0, 8) == {'node': 0, 'cpus': len(nodes[0][1]), 'source': 'device-order rule'} and pinned[-1] == sorted(nodes[0][1])
     assert bench.pin_rank(3, 8)['node'] == 0 and bench.pin_rank(4, 8)['node'] == 1 and bench.pin_rank(7, 8)['node'] == 1
     n = len(pinned)
     assert bench.pin_rank(0, 1) is None and len(pinned) == n               # one rank: nothing to separate
@@ -72,6 +73,60 @@ def test_rank_pinning_picks_the_numa_node_of_the_gpu(monkeypatch):
     monkeypatch.delenv('OG_BENCH_NUMA')
     monkeypatch.setattr(bench, 'numa_nodes', lambda: nodes[:1])
     assert bench.pin_rank(5, 8) is None and len(pinned) == n               # one node
+
+
+def _fake_sysfs(root, gpu_nodes, cpu_nodes=2):
+    """A sysfs tree with `cpu_nodes` CPU-only KFD nodes followed by one GPU node per entry of gpu_nodes (its NUMA node), render
+    minors counting DOWN (enumeration order != minor order, as on real hosts)."""
+    for i in range(cpu_nodes):
+        d = root / 'class/kfd/kfd/topology/nodes' / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count 64\nsimd_count 0\ndrm_render_minor -1\n')
+    for g, numa in enumerate(gpu_nodes):
+        d = root / 'class/kfd/kfd/topology/nodes' / str(cpu_nodes + g)
+        d.mkdir(parents=True)
+        minor = 128 + len(gpu_nodes) - 1 - g
+        (d / 'properties').write_text(f'cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {minor}\nlocation_id {g}\n')
+        dev = root / f'class/drm/renderD{minor}/device'
+        dev.mkdir(parents=True)
+        (dev / 'numa_node').write_text(f'{numa}\n')
+
+
+def test_rank_pinning_reads_the_gpu_numa_node_from_sysfs(tmp_path, monkeypatch):
+    """pin_rank looks the GPU's NUMA node up (KFD topology -> DRM render node -> PCI numa_node) instead of assuming that GPUs
+    hang off the nodes in device order: an enumeration where they do NOT (0 1 1 0 ...) must be followed; -1 / an unreadable
+    tree falls back to the rule and says so; HIP_VISIBLE_DEVICES reorders."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    layout = [1, 0, 0, 1, 1, 1, 0, -1]
+    _fake_sysfs(tmp_path, layout)
+    assert bench.gpu_numa_nodes(str(tmp_path), env={}) == layout
+    assert bench.gpu_numa_nodes(str(tmp_path), env={'HIP_VISIBLE_DEVICES': '3,0'}) == [1, 1]
+    assert bench.gpu_numa_nodes(str(tmp_path), env={'ROCR_VISIBLE_DEVICES': '1,2,3', 'HIP_VISIBLE_DEVICES': '2'}) == [1]
+    assert bench.gpu_numa_nodes(str(tmp_path), env={'HIP_VISIBLE_DEVICES': 'GPU-abcdef'}) is None
+    assert bench.gpu_numa_nodes(str(tmp_path / 'nothing'), env={}) is None
+    # a container that may open only ONE of the host's GPUs: the other nodes' properties are unreadable and are skipped,
+    # exactly as the runtime skips them -- device 0 is that GPU
+    solo = tmp_path / 'solo'
+    _fake_sysfs(solo, layout)
+    for g in range(8):
+        if g != 6:
+            (solo / 'class/kfd/kfd/topology/nodes' / str(2 + g) / 'properties').unlink()
+    assert bench.gpu_numa_nodes(str(solo), env={'HIP_VISIBLE_DEVICES': '0'}) == [layout[6]]
+    have = sorted(os.sched_getaffinity(0))
+    half = max(1, len(have) // 2)
+    nodes = [(0, have[:half]), (1, have[half:] or have[:half])]
+    monkeypatch.setattr(bench, 'numa_nodes', lambda: nodes)
+    real = bench.gpu_numa_nodes
+    monkeypatch.setattr(bench, 'gpu_numa_nodes', lambda: real(str(tmp_path), env={}))
+    pinned = []
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus: pinned.append(sorted(cpus)))
+    for r, want in enumerate(layout[:7]):
+        got = bench.pin_rank(r, 8)
+        assert got == {'node': want, 'cpus': len(nodes[want][1]), 'source': 'sysfs'} and pinned[-1] == sorted(nodes[want][1])
+    assert bench.pin_rank(7, 8) == {'node': 1, 'cpus': len(nodes[1][1]), 'source': 'device-order rule'}      # sysfs says -1
 
 
 def test_a_rank_that_dies_fails_the_whole_job_quickly():

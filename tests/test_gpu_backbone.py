@@ -395,91 +395,6 @@ def test_conv3x3_tiled_up2_equals_conv_then_upsample_add(dev, shape, dtype):
         assert not torch.equal(want, up1)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(8, 160, 160, 256, 4, False), (4, 64, 64, 128, 4, True), (12, 40, 40, 256, 3, True), (8, 40, 40, 384, 4, False), (8, 32, 32, 128, 2, False),
-                                  (4, 80, 80, 256, 4, True)])
-def test_conv3x3_tiled_chain_equals_layerwise_launches(dev, case, dtype):
-    """og_conv3x3_tiled_chain_* (dependent layers in one launch, workgroups of layer l + 1 waiting tile by tile for layer l) ==
-    the same layers as separate og_conv3x3_tiled_* / og_conv3x3_tiled_up2_* launches, bit for bit: residual structure (conv1 -> conv2 +
-    the block's input), 2 to 4 layers, both tile shapes, work-item chunks that cross images (halos handed over between XCDs), the
-    hourglass merge on the last layer; repeated launches, the workspace back to zero (its error word included) every time."""
-    n, h, w, c, layers, up_last = case
-    lib = _lib.load()
-    g = torch.Generator(device='cpu').manual_seed(h * 131 + c + layers)
-    cl = torch.channels_last
-    x = torch.randn(n, c, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
-    up1 = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
-    packs, biases = [], []
-    for _ in range(layers):
-        wt = (torch.randn(c, c, 3, 3, generator=g) * (1.0 / (9 * c)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
-        packed = torch.empty(wt.numel(), dtype=dtype, device=dev)
-        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), c, c, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
-        packs.append(packed)
-        biases.append((torch.randn(c, generator=g) * 0.1).to(dev))
-    st = _lib.stream_ptr(dev)
-
-    def plan(outs, up):
-        """(input, skip, out, up) per layer: odd layers close a residual block (skip = the block's input)"""
-        res, cur, blk = [], x, x
-        for l in range(layers):
-            last = l == layers - 1
-            res.append((cur, blk if l % 2 == 1 else None, None if (last and up is not None) else outs[l], up if last else None))
-            cur = outs[l]
-            if l % 2 == 1:
-                blk = cur
-        return res
-
-    want_outs = [torch.empty_like(x) for _ in range(layers)]
-    want_up = up1.clone(memory_format=torch.preserve_format) if up_last else None
-    for l, (xi, skip, out, up) in enumerate(plan(want_outs, want_up)):
-        need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, c)
-        assert need == 0
-        fn = _lib.lp(lib, 'og_conv3x3_tiled_up2' if up is not None else 'og_conv3x3_tiled', dtype)
-        _lib.check(fn(_lib.ptr(xi), _lib.ptr(packs[l]), _lib.ptr(biases[l]), _lib.ptr(skip) if skip is not None else None,
-                      _lib.ptr(up if up is not None else out), n, h, w, c, c, 1, None, 0, st), lib)
-    ws = torch.zeros(int(lib.og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=dev)
-    for rep in range(3):
-        got_outs = [torch.full_like(x, float('nan')) for _ in range(layers)]
-        got_up = up1.clone(memory_format=torch.preserve_format) if up_last else None
-        descs = [_lib.TiledLayerDesc(_lib.ptr(xi), _lib.ptr(packs[l]), _lib.ptr(biases[l]), _lib.ptr(skip) if skip is not None else None,
-                                     _lib.ptr(out) if out is not None else None, _lib.ptr(up) if up is not None else None, n, h, w, c, c, 1)
-                 for l, (xi, skip, out, up) in enumerate(plan(got_outs, got_up))]
-        assert _lib.tiled_chain_supported(descs)
-        _lib.tiled_chain(descs, dtype, ws, dev)
-        torch.cuda.synchronize()
-        for l in range(layers - (1 if up_last else 0)):
-            assert torch.equal(got_outs[l], want_outs[l]), f'{case} launch {rep} layer {l}'
-        if up_last:
-            assert torch.equal(got_up, want_up), f'{case} launch {rep}: merged tensor'
-        assert int(ws.view(torch.int32).abs().sum().item()) == 0, 'the launch must leave its workspace zero (error word included)'
-
-
-def test_conv3x3_tiled_chain_api_errors(dev):
-    lib = _lib.load()
-    cl = torch.channels_last
-    x = torch.zeros(8, 128, 32, 32, device=dev, dtype=torch.float16).contiguous(memory_format=cl)
-    y = torch.zeros_like(x)
-    z = torch.zeros_like(x)
-    b = torch.zeros(128, device=dev)
-    ws = torch.zeros(int(lib.og_conv3x3_tiled_chain_workspace_bytes()), dtype=torch.uint8, device=dev)
-    d = lambda i, o, **kw: _lib.TiledLayerDesc(_lib.ptr(i), _lib.ptr(x), _lib.ptr(b), None, _lib.ptr(o) if o is not None else None,
-                                               kw.get('up'), 8, kw.get('h', 32), 32, 128, 128, 1)
-    ok = [d(x, y), d(y, z)]
-    assert _lib.tiled_chain_supported(ok)
-    assert not _lib.tiled_chain_supported(ok[:1])                                  # one layer is a plain launch
-    assert not _lib.tiled_chain_supported(ok * 3)                                  # more than four layers
-    assert not _lib.tiled_chain_supported([d(x, y), d(y, z, h=16)])                # layers must share N, H, W
-    assert not _lib.tiled_chain_supported([d(x, y, up=_lib.ptr(z)), d(y, z)])      # the merge only on the last layer
-    assert not _lib.tiled_chain_supported([d(x, None), d(y, z)])                   # an inner layer needs its output
-    arr = (_lib.TiledLayerDesc * 2)(*ok)
-    st = _lib.stream_ptr(dev)
-    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, _lib.ptr(ws), 128, st) == _lib.OG_ENOSPC
-    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, None, ws.numel(), st) == _lib.OG_EINVAL
-    assert lib.og_conv3x3_tiled_chain_f16(arr, 1, _lib.ptr(ws), ws.numel(), st) == _lib.OG_EUNSUPPORTED
-    assert lib.og_conv3x3_tiled_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), st) == _lib.OG_OK
-    torch.cuda.synchronize()
-
-
 # (N, Hin, Win, Cin, Cout, stride, projection (H2, W2, Cin2, stride2) or None)
 BAND_SHAPES = [(8, 5, 5, 512, 512, 1, None), (8, 10, 10, 384, 384, 1, None), (2, 20, 20, 384, 384, 1, None),
                (8, 10, 10, 384, 512, 2, None), (2, 20, 20, 384, 384, 2, None), (8, 5, 5, 512, 512, 1, (10, 10, 384, 2)),
@@ -529,93 +444,6 @@ def test_conv_band_matches_torch(dev, shape, dtype):
         assert not torch.isnan(out.float()).any()
         err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
         assert err <= tol, f'{shape} skip={use_skip} relu={relu}: relative error {err}'
-
-
-def _band_chain_case(dev, dtype, n, hw, chans, seed):
-    """A chain shaped like the hourglass's residuals at one level: conv1 (ReLU), conv2 + skip (ReLU), ...; channel counts from
-    `chans` (a projection along K where a residual changes its width).  -> (descs, keep-alive tensors, outputs, inputs)"""
-    lib = _lib.load()
-    g = torch.Generator(device='cpu').manual_seed(seed)
-    cl = torch.channels_last
-    h = w = hw
-    x = torch.randn(n, chans[0], h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=cl)
-    descs, keep, outs, layers = [], [x], [], []
-    cur, cur_c = x, chans[0]
-    for bi, cout in enumerate(chans[1:]):
-        block_in, block_c = cur, cur_c
-        for half in (0, 1):
-            cin = cur_c
-            wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (9 * cin)) ** 0.5).to(dev).to(dtype).contiguous(memory_format=cl)
-            bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
-            proj = half == 1 and block_c != cout
-            wp = (torch.randn(cout, block_c, generator=g) * (1.0 / block_c) ** 0.5).to(dev).to(dtype).contiguous() if proj else None
-            packed = torch.empty(cout * (9 * cin + (block_c if proj else 0)), dtype=dtype, device=dev)
-            _lib.check(lib.og_conv_band_pack_w16(_lib.ptr(wt), _lib.ptr(wp) if proj else None, cin, cout, block_c if proj else 0,
-                                                 _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
-            out = torch.full((n, cout, h, w), float('nan'), dtype=dtype, device=dev).contiguous(memory_format=cl)
-            skip = block_in if (half == 1 and not proj) else None
-            d = _lib.BandLayerDesc(_lib.ptr(cur), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(skip) if skip is not None else None,
-                                   _lib.ptr(block_in) if proj else None, _lib.ptr(out), n, h, w, cin, cout, 1, 1,
-                                   h if proj else 0, w if proj else 0, block_c if proj else 0, 1)
-            descs.append(d)
-            layers.append((cur, wt, bias, skip, block_in if proj else None, wp))
-            keep += [wt, bias, packed, out] + ([wp] if proj else [])
-            outs.append(out)
-            cur, cur_c = out, cout
-    return descs, keep, outs, layers
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(8, 5, [512, 512, 512, 384]), (8, 10, [384, 384, 384]), (3, 7, [128, 64, 64, 96]), (2, 20, [384, 384])])
-def test_conv_band_chain_matches_layerwise(dev, case, dtype):
-    """og_conv_band_chain_* (dependent layers in ONE launch: per-XCD ticket queues, per-image completion counters, write-through
-    hand-off) vs the same layers launched one by one (bit for bit: same arithmetic) and vs fp32 torch; launched five times on one
-    workspace (it must come back zero), the sticky error word stays clear."""
-    import torch.nn.functional as F
-    n, hw, chans = case
-    lib = _lib.load()
-    descs, keep, outs, layers = _band_chain_case(dev, dtype, n, hw, chans, seed=hw * 100 + n)
-    ws = torch.zeros(lib.og_conv_band_chain_workspace_bytes(), dtype=torch.uint8, device=dev)
-    fn = _lib.lp(lib, 'og_conv_band', dtype)
-    for d in descs:      # reference: one launch per layer
-        _lib.check(fn(d.x, d.w_packed, d.bias, d.skip, d.x2, d.out, d.N, d.Hin, d.Win, d.Cin, d.Cout, d.stride, d.relu, d.H2, d.W2,
-                      d.Cin2, d.stride2, _lib.stream_ptr(dev)), lib)
-    ref = [o.clone() for o in outs]
-    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
-    for (xin, wt, bias, skip, x2, wp), r in zip(layers, ref):          # the layer-wise path itself against torch
-        t = F.conv2d(xin.float(), wt.float(), bias, 1, 1)
-        if x2 is not None:
-            t = t + F.conv2d(x2.float(), wp.float().view(wp.shape[0], -1, 1, 1))
-        if skip is not None:
-            t = t + skip.float()
-        t = F.relu(t)
-        assert ((r.float() - t).abs().max() / t.abs().max()).item() <= tol
-    for rep in range(5):
-        for o in outs:
-            o.fill_(float('nan'))
-        if rep == 3:      # uneven load: a bandwidth hog runs beside the chain
-            side = torch.cuda.Stream(dev)
-            with torch.cuda.stream(side):
-                junk = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
-                junk.fill_(1)
-        _lib.band_chain(descs, dtype, ws, dev)
-        torch.cuda.synchronize()
-        for li, (o, r) in enumerate(zip(outs, ref)):
-            assert torch.equal(o, r), f'{case} launch {rep} layer {li}: chained result differs from the layer-wise launch'
-        assert int(ws.view(torch.int32).abs().sum().item()) == 0, 'the launch must leave its workspace zero (error word included)'
-
-
-def test_conv_band_chain_rejects_bad_lists(dev):
-    lib = _lib.load()
-    descs, keep, outs, _ = _band_chain_case(dev, torch.float16, 2, 5, [64, 64], seed=1)
-    ws = torch.zeros(lib.og_conv_band_chain_workspace_bytes(), dtype=torch.uint8, device=dev)
-    arr = (_lib.BandLayerDesc * 2)(descs[1], descs[0])                   # layer 1 does not read layer 0
-    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == -4
-    arr = (_lib.BandLayerDesc * 2)(*descs)
-    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), 128, _lib.stream_ptr(dev)) == -2      # workspace too small
-    assert lib.og_conv_band_chain_f16(arr, 17, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == -4
-    assert lib.og_conv_band_chain_f16(arr, 2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)) == 0
-    torch.cuda.synchronize()
 
 
 def test_conv_band_rejects_bad_arguments(dev):
@@ -881,12 +709,11 @@ def test_engine_f16_matches_reference_golden(dev):
 
 
 @pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0"}, {"OG_ENGINE_TRUNK_FIRST": "0"}, {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_UP2": "0"},
-                                   {"OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"}, {"OG_ENGINE_DEEP_SHARED": "2"},
-                                   {"OG_CONV_BAND_MAX_PIXELS": "1024", "OG_CONV_BAND_CHAIN": "1"}, {"OG_CONV_TILED_CHAIN": "1"}])
+                                   {"OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"}, {"OG_ENGINE_DEEP_SHARED": "2"}])
 def test_engine_schedule_knobs(dev, knobs):
     """The engine's kept A/B switches (read at import): merges as their own launches instead of on the producing convolution's
     epilogue, up1 branch captured before the trunk below the fork, the small levels back on the split-K kernel with every up1
-    branch on its own stream, the inner branches sharing a stream from depth 2, the band kernel as chained launches -- the graph-engine tests again in a child process."""
+    branch on its own stream, the inner branches sharing a stream from depth 2 -- the graph-engine tests again in a child process."""
     import os
     import subprocess
     import sys

@@ -256,6 +256,85 @@ def test_run_images_from_raw_uint8_images(dev, monkeypatch):
     assert abs(back[0, 0, 0] - (250 - 1) / 2) < 1.0 and abs(back[0, 0, 1] - (333 - 1) / 2) < 1.0
 
 
+def test_run_images_fixed_height_engine_cache(dev, monkeypatch):
+    """--fixed-height (evaluate.py:150-156, the reference's best published setting: RescaleHighAbsolute + RightDownPad, batch 1,
+    the width varies): one engine per padded width, at most ENGINE_CACHE alive (least recently used goes), all of them sharing ONE
+    set of folded / tiled weights; results == poses_to_results(oracle.decode(recorded head outputs)) whichever engine ran."""
+    from offsetguided_amd import evaluate, transforms
+    from offsetguided_amd.models import engine as eng_mod
+    torch.manual_seed(0)
+    a = evaluate.evaluate_cli(['--no-pretrain', '--initialize-whole', 'False', '--topk', '32', '--thre-hmp', '0.04',
+                               '--person-thre', '0.04', '--dist-max', '40', '--long-edge', '256', '--batch-size', '1',
+                               '--print-freq', '1', '--fixed-height'])
+    model, _ = models.model_factory(a)
+    rng = np.random.default_rng(7)
+    sizes = [(100, 90), (100, 190), (100, 290), (120, 100), (100, 180), (90, 260), (100, 95)]   # -> widths 256, 512, 768, 256, 512, 768, 256
+    raw = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    loader = [([r], [None], [{'image_id': i + 1}]) for i, r in enumerate(raw)]
+    seen, built = [], []
+    build = decoder.decoder_factory
+
+    def recording_factory(args):
+        proc = build(args)
+        submit = proc.submit
+
+        def spy(features, **kw):
+            seen.append((features[0][0][-1].cpu().numpy().copy(), features[1][0][-1].cpu().numpy().copy()))
+            return submit(features, **kw)
+        proc.submit = spy
+        return proc
+    monkeypatch.setattr(decoder, 'decoder_factory', recording_factory)
+    engine_cls = models.InferenceEngine
+
+    def counting_engine(*args, **kw):
+        e = engine_cls(*args, **kw)
+        built.append(e)
+        return e
+    monkeypatch.setattr(models, 'InferenceEngine', counting_engine)
+    monkeypatch.setattr(evaluate, 'ENGINE_CACHE', 2)
+    results, ids = evaluate.run_images(a, data_loader=loader, model=model)
+    assert ids == [1, 2, 3, 4, 5, 6, 7]
+    assert [e.shape[3] for e in built] == [256, 512, 768, 256, 512, 768, 256]      # a cache of two never hits on this cycle of three ...
+    assert len({id(e._layers) for e in built}) == 1                                # ... but every build re-uses the same weights
+    assert sum(id(e._layers) == id(v[1]) for e in built[:1] for v in eng_mod._layer_cache.values()) == 1
+    monkeypatch.setattr(evaluate, 'ENGINE_CACHE', 4)
+    del built[:]
+    results2, ids2 = evaluate.run_images(a, data_loader=loader, model=model)
+    assert len(built) == 3 and ids2 == ids                                          # three shapes, three builds, four hits
+    pre = transforms.EvalPreprocess(256, fixed_height=True)
+    for res, seen_part in ((results, seen[:7]), (results2, seen[7:])):
+        exp_results, exp_ids = [], []
+        for (hm, off), (imgs, _, metas) in zip(seen_part, loader):
+            _, pmetas = pre(list(imgs), image_ids=[m['image_id'] for m in metas])
+            assert hm.shape[2] * 4 == 256 and hm.shape[3] * 4 % 128 == 0
+            poses, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, **OFLAGS)
+            for image_poses, meta in zip(poses, pmetas):
+                evaluate.poses_to_results(image_poses, meta, exp_results, exp_ids)
+        assert exp_ids == ids and len(res) == len(exp_results)
+        for got, exp in zip(res, exp_results):
+            assert got['image_id'] == exp['image_id'] and got['keypoints'] == exp['keypoints'] and abs(got['score'] - exp['score']) <= 1e-6
+
+
+def test_shared_layers_follow_the_module_weights(dev):
+    """Engines share folded weights only while the module's weights are the same: an in-place update (optimizer step,
+    load_state_dict, a write through .data) gives the next engine a fresh fold."""
+    from offsetguided_amd.models import engine as eng_mod
+    a = make_args(batch=1)
+    model, _ = models.model_factory(a)
+    e1 = models.InferenceEngine(model, 1, 128, 128, device=dev, use_graph=False)
+    e2 = models.InferenceEngine(model, 1, 128, 256, device=dev, use_graph=False)
+    assert e1._layers is e2._layers
+    x = torch.from_numpy(synth.noise_batch(3, (1, 3, 128, 128))).to(dev)
+    before = e1(x)[0][0][-1].clone()
+    with torch.no_grad():
+        model.headnets[0].hp_convs[-1].weight.data.mul_(2.0)          # .data: no version bump, the checksum catches it
+    e3 = models.InferenceEngine(model, 1, 128, 128, device=dev, use_graph=False)
+    assert e3._layers is not e1._layers
+    after = e3(x)[0][0][-1]
+    assert not torch.equal(before, after)
+    assert torch.equal(e1(x)[0][0][-1], before)                       # the old engine keeps the weights it was built from
+
+
 # ---------------------------------------------------------------------------------- precision statement
 def _pose_keypoints(poses):
     """{global_idx: score} over the keypoints of all poses of one image."""

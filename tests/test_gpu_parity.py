@@ -10,7 +10,7 @@ import torch
 import oracle
 from offsetguided_amd import _lib, decoder, synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
+from helpers import (FLAGS, SKELETON_CASES, case_flags, case_headnet, case_skeleton, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
                      split_poses)
 
 pytestmark = pytest.mark.gpu
@@ -25,15 +25,20 @@ def dev():
     return torch.device("cuda:0")
 
 
-def processor(batch=2, **over):
+def processor(batch=2, headnet='omp', **over):
     p = argparse.ArgumentParser()
     decoder.decoder_cli(p)
     f = dict(FLAGS, **over)
     a = p.parse_args(['--topk', str(f['topk']), '--thre-hmp', str(f['thre_hmp']), '--person-thre',
                       str(f['person_thre']), '--dist-max', str(f['dist_max']), '--min-len', str(f['min_len'])])
-    a.headnets, a.strides, a.batch_size = ['hmp', 'omp'], [4, 4], batch
+    a.headnets, a.strides, a.batch_size = ['hmp', headnet], [4, 4], batch
     a.include_scale = a.include_jitter_offset = False
     return decoder.decoder_factory(a)
+
+
+def case_processor(g):
+    """The processor a pipeline fixture was generated with: its offset head (skeleton) and --topk."""
+    return processor(int(g["batch"]), case_headnet(g), topk=case_flags(g)["topk"])
 
 
 def features(hm, off, dev):
@@ -152,7 +157,7 @@ def test_joint_dets_lowres_degenerate(dev):
 @pytest.mark.parametrize("name", PIPE_CASES)
 def test_generate_poses_fused_golden(dev, name):
     g, hm, off = load_case(name)
-    proc = processor(int(g["batch"]))
+    proc = case_processor(g)
     proc.fused_upsample = True
     feats = features(hm, off, dev)
     limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)).cpu().numpy()
@@ -170,10 +175,10 @@ def test_topk_errors(dev):
 
 
 # ------------------------------------------------------------------ limbs (a9-a10)
-@pytest.mark.parametrize("name", ["pipe256_p6", "pipe256_p20", "pipe640"])
+@pytest.mark.parametrize("name", ["pipe256_p6", "pipe256_p20", "pipe640", "pipe256_omp31_p6", "pipe256_omp44_k48_p20"])
 def test_collect_limbs_both_offset_forms(dev, name):
     g, hm, off = load_case(name)
-    proc = processor(int(g["batch"]))
+    proc = case_processor(g)
     hr = oracle.bicubic4(hm)
     ohr = oracle.bilinear4(off)
     t_hr = torch.from_numpy(hr).to(dev)
@@ -253,6 +258,49 @@ def _adversarial(rng, K, skeleton, hw=4096):
     return limbs
 
 
+@pytest.mark.parametrize("sk_name,K,variant", [("COCO_PERSON_SKELETON", 32, "lds"), ("DENSER_COCO_PERSON_SKELETON", 48, "table in the workspace"),
+                                               ("DENSER_COCO_PERSON_SKELETON", 64, "table + staged rows in the workspace"),
+                                               ("COCO_PERSON_WITH_REDUNDANT_SKELETON", 128, "table + staged rows in the workspace"),
+                                               ("KINEMATIC_TREE_SKELETON", 200, "table + staged rows in the workspace")])
+def test_grouping_any_skeleton_any_topk(dev, sk_name, K, variant):
+    """K3 serves every skeleton the reference defines at any realistic --topk (the reference's GreedyGroup has no limit,
+    decoder/group.py:39-240; its CLI default is 48, decoder/factory.py:154): when L*k does not fit in LDS the partial-skeleton table,
+    then the staged candidate rows, live in the caller's workspace.  Collision-heavy limbs with many candidates per type, vs
+    the oracle, bit for bit."""
+    sk = getattr(cd, sk_name)
+    cases = []
+    for i in range(6):
+        rng = synth.HashRng(990000 + 17 * K + i)
+        lim = _adversarial(rng, K, sk)
+        # fill the tail rows (sub-threshold fillers in _adversarial) with more real candidates so that many rows survive
+        rng2 = synth.HashRng(991000 + 17 * K + i)
+        P = 14
+        xy = rng2.uniform(P * 17 * 2, 1.0, 400.0).reshape(P, 17, 2).round()
+        v = rng2.uniform(P * 17, 0.05, 1.0).reshape(P, 17)
+        for l, (a, b) in enumerate(sk):
+            sc = rng2.uniform(P, 0.01, 1.0)
+            swap = rng2.integers(P, 0, P - 1)
+            for q in range(min(P, K)):
+                t = int(swap[q]) if q % 3 == 0 else q
+                lim[l, K - 1 - q] = [xy[q, a, 0], xy[q, a, 1], v[q, a], xy[t, b, 0], xy[t, b, 1], v[t, b],
+                                     a * 4096 + 100 + q, b * 4096 + 100 + t, 3.0, 10.0, sc[q], 4.0, 4.0]
+        cases.append(lim)
+    G = decoder.GreedyGroup(0.04, sort_dim=2, dist_max=40.0, use_scale=False, skeleton=sk)
+    got = G.group_batch(torch.from_numpy(np.stack(cases)).to(dev))
+    for lim, p in zip(cases, got):
+        ref = oracle.greedy_group(lim, sk, 17, 0.04, 40.0)
+        assert len(ref) > 0 and p.shape == ref.shape and (p == ref).all(), variant
+
+
+def test_grouping_capacity_limit_is_an_error(dev):
+    """Beyond the documented capacity (16 B of LDS per candidate + 108 B per table row) K3 refuses with
+    OG_EUNSUPPORTED and a message -- never a wrong result, never a silent CPU path."""
+    sk = cd.DENSER_COCO_PERSON_SKELETON
+    G = decoder.GreedyGroup(0.04, dist_max=40.0, skeleton=sk)
+    with pytest.raises(_lib.OgError, match="LDS"):
+        G.group_device(torch.zeros(1, len(sk), 256, 13, device=dev))
+
+
 def test_grouping_table_overflow_retry(dev):
     """More live partial skeletons than the LDS table holds -> flagged, retried with a larger table."""
     sk = cd.COCO_PERSON_SKELETON
@@ -271,27 +319,31 @@ def test_grouping_table_overflow_retry(dev):
 
 
 # ------------------------------------------------------------------ flip merge (a4) + whole pipeline
-@pytest.mark.parametrize("name", ["pipe256_flip_p6", "pipe640_flip", "pipe256_flipcat_p6", "pipe640_flipcat"])
+@pytest.mark.parametrize("name", ["pipe256_flip_p6", "pipe640_flip", "pipe256_flipcat_p6", "pipe640_flipcat"] +
+                         [c for c in SKELETON_CASES if "_flip" in c])
 def test_flip_merge_exact(dev, name):
     g, hm, off = load_case(name)
-    proc = processor(int(g["batch"]))
+    proc = case_processor(g)
     cat = is_cat(g)
     mh, _, mo, _, nd = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], cat, 2)
-    rh, ro = (oracle.flip_cat if cat else oracle.flip_merge)(hm, off, *flip_tables())
+    rh, ro = (oracle.flip_cat if cat else oracle.flip_merge)(hm, off, *flip_tables(case_skeleton(g)))
     assert nd == (4 if cat else 2)
     assert mo.shape == ((hm.shape[0], off.shape[1]) + hm.shape[2:] if cat else ro.shape)  # factory.py:127 view
     assert (mh.cpu().numpy() == rh).all() and (mo.cpu().numpy().ravel() == ro.ravel()).all()
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 256), (8, 640, 640), (3, 384, 512)])
-def test_flip_fold_equals_flip_merge(dev, shape):
+@pytest.mark.parametrize("shape,headnet,topk", [((2, 256, 256), "omp", 32), ((8, 640, 640), "omp", 32), ((3, 384, 512), "omp", 32),
+                                                ((2, 256, 256), "omp16", 32), ((2, 256, 320), "omp31", 48),
+                                                ((2, 256, 256), "omp44", 48), ((3, 192, 256), "omp25", 20)])
+def test_flip_fold_equals_flip_merge(dev, shape, headnet, topk):
     """flip_augment folded into its consumers (og_upsample_bicubic4_flip_f32, og_generate_limbs_flip_f32: the merge of
     decoder/factory.py:98-146 computed on the loads) == og_flip_merge_f32 followed by the plain kernels, bit for bit: the hi-res
     heatmaps, the limbs (every column) and the poses; and the folded pipeline against the oracle on two images."""
     n, h, w = shape
-    hm, off = synth.synth_batch(31 + n, n, h, w, flip=True)
+    skel = decoder.factory.parse_heads(headnet, 4)["skeleton"]
+    hm, off = synth.synth_batch(31 + n, n, h, w, flip=True, skeleton=skel)
     t_hm, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
-    proc = processor(n)
+    proc = processor(n, headnet, topk=topk)
     assert proc.fold_flip
     kp_perm, (limb_perm, reserve) = proc.keypoints_flips, proc.limbs_flips
     mh, _, mo, _, _ = proc.flip_augment(t_hm, [], t_off, [], False, 2)
@@ -308,17 +360,17 @@ def test_flip_fold_equals_flip_merge(dev, shape):
     poses_ref = proc.generate_poses(feats, flip_test=True)
     assert len(poses_fold) == len(poses_ref) == n and all(np.array_equal(a_, b_) for a_, b_ in zip(poses_fold, poses_ref))
     sel = [0, 1, n, n + 1]
-    ref, _ = oracle.decode(hm[sel], off[sel], cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+    ref, _ = oracle.decode(hm[sel], off[sel], skel, topk_k=topk, thre_hmp=FLAGS["thre_hmp"],
                            min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
-                           flip=flip_tables())
+                           flip=flip_tables(skel))
     assert_poses_match(ref, poses_fold[:2], SCORE_TOL)
 
 
-@pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat"])
+@pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat", "pipe256_omp16_flipcat_p6", "pipe256_omp44_flipcat_p6"])
 def test_collect_limbs_4d_offsets_hires_form(dev, name):
     """The reference's own call (collect.py:62 with vector_nd=4 on materialised hi-res offsets) == low-res sampling."""
     g, hm, off = load_case(name)
-    proc = processor(int(g["batch"]))
+    proc = case_processor(g)
     mh, _, mo, _, nd = proc.flip_augment(torch.from_numpy(hm).to(dev), [], torch.from_numpy(off).to(dev), [], True, 2)
     hr = decoder.factory.upsample4(mh, 'bicubic')
     ohr = decoder.factory.upsample4(mo, 'bilinear')
@@ -330,7 +382,7 @@ def test_collect_limbs_4d_offsets_hires_form(dev, name):
 def test_generate_poses_golden(dev, name):
     """Drop-in surface: decoder_factory(args).generate_poses(features, flip_test) vs the reference's output."""
     g, hm, off = load_case(name)
-    proc = processor(int(g["batch"]))
+    proc = case_processor(g)
     feats = features(hm, off, dev)
     limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)).cpu().numpy()
     assert_limbs_match(g["limbs"], limbs, SCORE_TOL)

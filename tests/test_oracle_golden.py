@@ -6,7 +6,7 @@ import pytest
 import oracle
 from offsetguided_amd import synth
 from offsetguided_amd.config import coco_data as cd
-from helpers import (FLAGS, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
+from helpers import (FLAGS, case_flags, case_skeleton, GOLDEN, PIPE_CASES, assert_limbs_match, assert_poses_match, flip_tables, is_cat, load_case, jitter_case_inputs, scale_case_inputs,
                      sha, split_poses)
 
 
@@ -26,13 +26,14 @@ def test_stage_units():
 @pytest.mark.parametrize("name", PIPE_CASES)
 def test_pipeline_case(name):
     g, hm, off = load_case(name)
-    flip = flip_tables() if int(g["flip"]) else None
+    FLAGS, skel = case_flags(g), case_skeleton(g)
+    flip = flip_tables(skel) if int(g["flip"]) else None
     cat = is_cat(g)
     merge = oracle.flip_cat if cat else oracle.flip_merge
     if flip:
         mh, mo = merge(hm, off, *flip)
         assert [sha(mh), sha(mo)] == list(g["merged_sha"])
-    poses, mid = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
+    poses, mid = oracle.decode(hm, off, skel, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"],
                                min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"],
                                dist_max=FLAGS["dist_max"], flip=flip, cat_flip_offs=cat)
     assert sha(mid["hm_hr"]) == str(g["hm_hr_sha"])
@@ -44,7 +45,7 @@ def test_pipeline_case(name):
     ohr = oracle.bilinear4(merged_off)
     assert sha(ohr) == str(g["off_hr_sha"])
     l2 = oracle.collect_limbs(mid["scores"], mid["inds"], ohr, False, mid["hm_hr"].shape[-2:],
-                              cd.COCO_PERSON_SKELETON, FLAGS["thre_hmp"], FLAGS["min_len"], vector_nd=4 if cat else 2)
+                              skel, FLAGS["thre_hmp"], FLAGS["min_len"], vector_nd=4 if cat else 2)
     assert (l2 == mid["limbs"]).all()
 
 
@@ -139,15 +140,17 @@ def test_jitter_head_case(name):
 
 
 # ---- the reference-shaped Python restatement (bench.py's cpu_baseline, kind "restatement") ----
-@pytest.mark.parametrize("name", ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe640", "pipe640_flip"])
+@pytest.mark.parametrize("name", ["pipe256_p0", "pipe256_p1", "pipe256_p6", "pipe256_p20", "pipe256_flip_p6", "pipe640", "pipe640_flip",
+                                  "pipe256_omp16_flip_p6", "pipe256_omp44_k48_p20", "pipe256_omp25_p6", "pipe640_omp31_k48_flip"])
 def test_restatement_pipeline_case(name):
     """oracle/restatement.py (torch-CPU ops + numpy grouping in a Pool, decoder/factory.py:52-96 shaped) against the
     reference's own outputs: candidate lists, limbs and poses."""
     import torch
     from oracle import restatement as rs
     g, hm, off = load_case(name)
-    flip = flip_tables() if int(g["flip"]) else None
-    dec = rs.Decoder(cd.COCO_PERSON_SKELETON, 2, k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"], min_len=FLAGS["min_len"],
+    FLAGS, skel = case_flags(g), case_skeleton(g)
+    flip = flip_tables(skel) if int(g["flip"]) else None
+    dec = rs.Decoder(skel, 2, k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"], min_len=FLAGS["min_len"],
                      person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
                      flip=(flip[0], flip[1], sorted(flip[2])) if flip else None)
     try:

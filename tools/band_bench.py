@@ -72,18 +72,6 @@ def main():
                 _lib.check(fn(_lib.ptr(acts[l % 3]), _lib.ptr(packed[l]), _lib.ptr(bias), _lib.ptr(acts[(l + 2) % 3]), None,
                               _lib.ptr(acts[(l + 1) % 3]), n, h, w, cin, cout, 1, 1, 0, 0, 0, 1, _lib.stream_ptr(dev)), lib)
             row += f'  band {graph_time(band, a.reps):6.2f} cold {graph_time(band, a.reps, cold=False):6.2f} warm'
-            # the same layers as ONE chained launch (distinct output buffers: reps + 1 activations)
-            cacts = [acts[0]] + [torch.empty_like(acts[0]) for _ in range(a.reps)]
-            descs = [_lib.BandLayerDesc(_lib.ptr(cacts[l]), _lib.ptr(packed[l]), _lib.ptr(bias), _lib.ptr(cacts[l - 1]) if l else None, None,
-                                        _lib.ptr(cacts[l + 1]), n, h, w, cin, cout, 1, 1, 0, 0, 0, 1) for l in range(a.reps)]
-            cws = torch.zeros(lib.og_conv_band_chain_workspace_bytes(), dtype=torch.uint8, device=dev)
-
-            def chain(l):
-                if l == 0:
-                    _lib.band_chain(descs, dt, cws, dev)
-            row += f'  chained {graph_time(chain, a.reps):6.2f} cold {graph_time(chain, a.reps, cold=False):6.2f} warm'
-            torch.cuda.synchronize()
-            assert int(cws.view(torch.int32).abs().sum().item()) == 0, 'chain workspace not zero (error word?)'
         # split-K kernel
         ws = torch.zeros(lib.og_conv2d_workspace_bytes(n, h, w, cin, cout, 3, 1), dtype=torch.uint8, device=dev)
         fn2 = _lib.lp(lib, 'og_conv2d', dt)

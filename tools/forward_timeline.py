@@ -9,7 +9,7 @@ import sys
 def short(n):
     for key, name in (('conv3x3_tiled_kernel<16', 'C1 tiled 16x16'), ('conv3x3_tiled_kernel<20', 'C1 tiled 20x4'), ('conv3x3_tiled_kernel<40', 'C1 tiled 40x4'),
                       ('conv3x3s2_tiled', 'C1 tiled stride 2'), ('conv1x1_tiled_kernel<128', 'pointwise'), ('conv1x1_tiled_kernel<64', 'heads'),
-                      ('conv_band_kernel<2', 'C3 band 5x5'), ('conv_band_kernel<4', 'C3 band 10x10 s2'), ('conv_band_kernel<7', 'C3 band 10x10'), ('conv_band_chain', 'C3 band chain'), ('merge_collect', 'K1 merge_collect'), ('halo_kernel<16', 'C1 halo 16x16'), ('halo_kernel<40', 'C1 halo 40x4'), ('conv3x3_kernel', 'C2 split-K'),
+                      ('conv_band_kernel<2', 'C3 band 5x5'), ('conv_band_kernel<4', 'C3 band 10x10 s2'), ('conv_band_kernel<7', 'C3 band 10x10'), ('merge_collect', 'K1 merge_collect'), ('halo_kernel<16', 'C1 halo 16x16'), ('halo_kernel<40', 'C1 halo 40x4'), ('conv3x3_kernel', 'C2 split-K'),
                       ('stem7x7', 'stem7x7'), ('upsample2_add', 'upsample2_add'), ('bias_act', 'bias_act'),
                       ('nhwc_slice', 'nhwc_slice_to_nchw'), ('band_topk', 'K1 band_topk'), ('merge_bands', 'K1 merge_bands'),
                       ('collect_limbs', 'K2 collect_limbs'), ('greedy_group', 'K3 greedy_group'), ('bicubic4', 'K1a bicubic4')):

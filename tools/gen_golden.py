@@ -53,13 +53,13 @@ def load_reference():
     return decoder
 
 
-def ref_processor(decoder, batch, **over):
+def ref_processor(decoder, batch, headnet='omp', **over):
     p = argparse.ArgumentParser()
     decoder.decoder_cli(p)
     f = dict(FLAGS, **over)
     a = p.parse_args(['--topk', str(f['topk']), '--thre-hmp', str(f['thre_hmp']), '--person-thre',
                       str(f['person_thre']), '--dist-max', str(f['dist_max']), '--min-len', str(f['min_len'])])
-    a.headnets = ['hmp', 'omp']
+    a.headnets = ['hmp', headnet]
     a.strides = [4, 4]
     a.batch_size = batch
     a.include_scale = False
@@ -96,9 +96,16 @@ def check_poses(ref, mine, tag):
     return worst
 
 
-def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage=True, cat=False):
-    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=n_persons)
-    proc = ref_processor(decoder, batch)
+def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage=True, cat=False, headnet='omp', topk=None):
+    """One pipeline fixture.  `headnet` selects the skeleton the way the reference's CLI does (decoder/factory.py:211-225:
+    omp = omp19 = COCO_PERSON_SKELETON, omp16, omp31, omp44, omp25); `topk` overrides FLAGS['topk'] (the reference's CLI
+    default is 48, decoder/factory.py:154)."""
+    FLAGS = dict(globals()['FLAGS'], topk=topk or globals()['FLAGS']['topk'])
+    SKEL = [tuple(c) for c in decoder.factory.parse_heads(headnet, 4)['skeleton']]   # the REFERENCE's table
+    from offsetguided_amd.decoder.factory import parse_heads as my_parse_heads
+    assert [tuple(c) for c in my_parse_heads(headnet, 4)['skeleton']] == SKEL, f'{headnet}: skeleton table differs'
+    hm, off = synth.synth_batch(seed, batch, size, size, flip=flip, n_persons=n_persons, skeleton=SKEL)
+    proc = ref_processor(decoder, batch, headnet, topk=FLAGS['topk'])
     # --- the reference, stage by stage (decoder/factory.py:52-96) ---
     thm, toff = torch.from_numpy(hm), torch.from_numpy(off)
     if flip:
@@ -118,13 +125,13 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
     # --- the oracle on the same inputs ---
     fl = None
     if flip:
-        perm, rev = offset_hflip(COCO_KEYPOINTS, COCO_PERSON_SKELETON)
+        perm, rev = offset_hflip(COCO_KEYPOINTS, SKEL)
         fl = (heatmap_hflip(COCO_KEYPOINTS), perm, rev)
         o_hm, o_off = (oracle.flip_cat if cat else oracle.flip_merge)(hm, off, *fl)
         # the reference hands the cat form on as a (2N, 2L, h, w) VIEW of the same (N, 4L, h, w) memory
         assert (o_hm == m_hm.numpy()).all() and (o_off.ravel() == m_off.numpy().ravel()).all(), f'{name}: flip merge'
         m_off = m_off.reshape(o_off.shape)
-    o_poses, o_mid = oracle.decode(hm, off, COCO_PERSON_SKELETON, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
+    o_poses, o_mid = oracle.decode(hm, off, SKEL, topk_k=FLAGS['topk'], thre_hmp=FLAGS['thre_hmp'],
                                    min_len=FLAGS['min_len'], person_thre=FLAGS['person_thre'],
                                    dist_max=FLAGS['dist_max'], flip=fl, cat_flip_offs=cat)
     assert (o_mid['hm_hr'] == hr.numpy()).all(), f'{name}: bicubic not bit-exact'
@@ -138,16 +145,16 @@ def pipeline_case(decoder, name, seed, batch, size, flip, n_persons, store_stage
     ds = 0.0
     if all_pos:
         ds = check_limbs(limbs, o_mid['limbs'], name)
-        o_l2 = oracle.collect_limbs(o_mid['scores'], o_mid['inds'], o_ohr, False, hr.shape[-2:], COCO_PERSON_SKELETON,
+        o_l2 = oracle.collect_limbs(o_mid['scores'], o_mid['inds'], o_ohr, False, hr.shape[-2:], SKEL,
                                     FLAGS['thre_hmp'], FLAGS['min_len'], vector_nd=nd)
         assert (o_l2 == o_mid['limbs']).all(), f'{name}: low-res sampling != hi-res gather'
     dp = check_poses(poses, o_poses, name)
     # oracle grouping fed with the REFERENCE limbs must agree exactly (isolates a12)
     for i in range(batch):
-        g = oracle.greedy_group(limbs[i], COCO_PERSON_SKELETON, 17, FLAGS['person_thre'], FLAGS['dist_max'])
+        g = oracle.greedy_group(limbs[i], SKEL, 17, FLAGS['person_thre'], FLAGS['dist_max'])
         assert g.shape == poses[i].shape and (g == poses[i]).all(), f'{name}: grouping on ref limbs'
 
-    out = dict(seed=seed, batch=batch, size=size, flip=int(flip), cat=int(cat), n_persons=-1 if n_persons is None else n_persons,
+    out = dict(headnet=np.array(headnet), topk=FLAGS['topk'], seed=seed, batch=batch, size=size, flip=int(flip), cat=int(cat), n_persons=-1 if n_persons is None else n_persons,
                in_sha=np.array([sha(hm), sha(off)]), hm_hr_sha=np.array(sha(hr.numpy())),
                off_hr_sha=np.array(sha(ohr.numpy())), all_positive=int(all_pos),
                scores=sc, inds=idx, limbs=limbs, n_poses=np.array([len(p) for p in poses]),
@@ -358,6 +365,22 @@ def stage_units():
     print('stage units: bicubic/bilinear/NMS/top-k bit-exact')
 
 
+def skeleton_cases(decoder):
+    """The head configurations the drop-in surface accepts besides the default (decoder/factory.py:211-225): K1 -> K2 -> K3
+    with and without the flip merge (limb_perm / reserve of THAT skeleton, config/coco_data.py:130-153) and with
+    cat_flip_offs; omp44 also at the CLI's default --topk 48 (decoder/factory.py:154)."""
+    for i, hn in enumerate(['omp16', 'omp31', 'omp44', 'omp25']):
+        # (seed 703 has two equal sub-threshold peaks in one plane: torch.topk's order of ties is unspecified, the strict
+        # check below refuses such a fixture)
+        pipeline_case(decoder, f'pipe256_{hn}_p6', (700 if i < 3 else 740) + i, 2, 256, False, 6, headnet=hn)
+        pipeline_case(decoder, f'pipe256_{hn}_flip_p6', 710 + i, 2, 256, True, 6, headnet=hn)
+        pipeline_case(decoder, f'pipe256_{hn}_flipcat_p6', 720 + i, 2, 256, True, 6, cat=True, headnet=hn)
+    pipeline_case(decoder, 'pipe256_omp44_k48_p20', 730, 2, 256, False, 20, headnet='omp44', topk=48)
+    pipeline_case(decoder, 'pipe256_omp44_k48_flip_p20', 731, 2, 256, True, 20, headnet='omp44', topk=48)
+    pipeline_case(decoder, 'pipe640_omp31_k48_flip', 732, 1, 640, True, None, headnet='omp31', topk=48)
+    pipeline_case(decoder, 'pipe256_omp19_k48_p6', 733, 2, 256, False, 6, headnet='omp19', topk=48)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -370,6 +393,9 @@ def main():
     scale_case(decoder, 'scale256', 401, 2, 256, False)
     scale_case(decoder, 'scale256_flip', 402, 2, 256, True)
     if '--cat-only' in sys.argv:
+        return
+    skeleton_cases(decoder)
+    if '--skeletons-only' in sys.argv:
         return
     stage_units()
     grouping_cases(decoder, n_fuzz=1500, n_store=60)
