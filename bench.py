@@ -485,7 +485,7 @@ def main():
                      'k0_us': round(float(np.mean(f_stage['k0_flip_merge'])), 2) if 'k0_flip_merge' in f_stage else 0.0,   # 0: the merge rides on K1a / K1
                      'k1a_upsample_us': round(float(np.mean(f_stage['k1a_upsample'])), 2),
                      'k1_generate_limbs_us': round(float(np.mean(f_stage['k1_generate_limbs'])), 2),
-                     'workload': f'bs{a.batch} {a.size}x{a.size} + flip-test: {2 * a.batch} images through the backbone per step, '
+                     'workload': f'bs{a.batch} {a.size}x{a.size} + flip-test: {2 * a.batch} images through the backbone per step, ' +
                                  ('K0 flip merge as its own pass' if 'k0_flip_merge' in f_stage else 'flip merge folded into the loads of K1a / K1 (no K0 pass)') + ', full decoder (BASELINE configs[2])'}
         del fpipe
 
