@@ -158,6 +158,27 @@ int og_generate_limbs_flip_f32(const float *hmps_hr, const float *offs_pair, con
                                float min_len, float resize_factor, float *topk_scores, int64_t *topk_inds, float *limbs,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- K1-fused (the production path): generate_limbs straight from the STRIDE-4 head outputs.  The x4 bicubic of
+ * decoder/factory.py:74-75 runs inside the NMS kernel (bit-identical to og_upsample_bicubic4_f32), offsets / scale / jitter maps are
+ * sampled at the peaks: neither hi-res tensor of factory.py:74-88 is built.  Same limbs, same optional (N,C,k) lists, same two
+ * launches and the same workspace as og_generate_limbs_f32 on (N,C,4h,4w): og_generate_limbs_workspace_bytes(N, C, 4h, 4w, k).
+ *   hmps_lr (N,C,h,w), offs_lr (N,vector_nd*L,h,w); scales_lr (N,C,h,w) with scales_mode 2 / 3 (bicubic / bilinear) or NULL / 0;
+ *   jitter_lr (N,2,h,w) with jitter_mode 3 or NULL / 0.
+ * og_generate_limbs_fused_flip_f32: flip-test (decoder/factory.py:98-146, averaged form, 2-component offsets, no scale / jitter
+ *   head) folded into both consumers: hm_pair_lr (2N,C,h,w), offs_pair_lr (2N,2L,h,w) = head outputs of [images | mirrored images];
+ *   kp_perm int32[C], limb_perm / reserve_mask int32[L] device arrays (config.heatmap_hflip / offset_hflip).  Bit-identical to
+ *   og_flip_merge_f32 + og_generate_limbs_fused_f32. */
+int og_generate_limbs_fused_f32(const float *hmps_lr, const float *offs_lr, int vector_nd, const float *scales_lr, int scales_mode,
+                                const float *jitter_lr, int jitter_mode, int N, int C, int h, int w, const int32_t *jf,
+                                const int32_t *jt, int L, int k, float thre_hmp, float min_len, float resize_factor,
+                                float *topk_scores, int64_t *topk_inds, float *limbs, void *workspace, size_t workspace_bytes,
+                                void *stream);
+int og_generate_limbs_fused_flip_f32(const float *hm_pair_lr, const int32_t *kp_perm, const float *offs_pair_lr,
+                                     const int32_t *limb_perm, const int32_t *reserve_mask, int N, int C, int h, int w,
+                                     const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
+                                     float resize_factor, float *topk_scores, int64_t *topk_inds, float *limbs, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 /* ---- a12: GreedyGroup.group_skeletons  decoder/group.py:39-185 (+ :187-240) ----
  * One workgroup per image, device resident (replaces .cpu().numpy() + Pool.starmap,
  * decoder/factory.py:91-94).

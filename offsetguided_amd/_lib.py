@@ -31,6 +31,8 @@ SIGNATURES = {
     "og_hmp_nms_f32": (_i, [_vp, _l, _i, _i, _vp, _vp]),
     "og_topk_channel_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "og_nms_topk_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "og_generate_limbs_fused_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "og_generate_limbs_fused_flip_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "og_upsample_nms_topk_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "og_topk_workspace_bytes": (_sz, [_l, _i, _i, _i]),
     "og_collect_limbs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp]),

@@ -38,17 +38,28 @@ __device__ __forceinline__ OgRow4 og_cubic_xpass(float c0, const float (*wx)[4])
     return o;
 }
 
-// one hi-res pixel of the x4 bicubic upsample of a low-res plane (same rounding as K1a)
-__device__ __forceinline__ float og_bicubic4_at(const float *__restrict__ lr, int h, int w, int Y, int X)
+// one hi-res pixel of the x4 bicubic upsample of a low-res plane (same rounding as K1a); lrb: the mirrored partner plane of the
+// flip-test merge or null -- a source value is then (lr[y][x] + lrb[y][w-1-x]) / 2 (og_flip_merge_f32's arithmetic)
+__device__ __forceinline__ float og_bicubic4_at(const float *__restrict__ lr, const float *__restrict__ lrb, int h, int w, int Y, int X)
 {
     const int qy = Y >> 2, ry = Y & 3, by = (ry < 2) ? qy - 1 : qy;
     const int qx = X >> 2, rx = X & 3, bx = (rx < 2) ? qx - 1 : qx;
     float rowv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float *r = lr + (size_t)min(max(by - 1 + j, 0), h - 1) * w;
-        rowv[j] = og_cubic_chain(r[min(max(bx - 1, 0), w - 1)], r[min(max(bx, 0), w - 1)], r[min(max(bx + 1, 0), w - 1)],
-                                 r[min(max(bx + 2, 0), w - 1)], og_cubic_w[rx]);
+        const size_t ro = (size_t)min(max(by - 1 + j, 0), h - 1) * w;
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = min(max(bx - 1 + i, 0), w - 1);
+            t[i] = lrb ? (lr[ro + c] + lrb[ro + (w - 1 - c)]) / 2.f : lr[ro + c];
+        }
+        rowv[j] = og_cubic_chain(t[0], t[1], t[2], t[3], og_cubic_w[rx]);
     }
     return og_cubic_chain(rowv[0], rowv[1], rowv[2], rowv[3], og_cubic_w[ry]);
+}
+
+__device__ __forceinline__ float og_bicubic4_at(const float *__restrict__ lr, int h, int w, int Y, int X)
+{
+    return og_bicubic4_at(lr, nullptr, h, w, Y, X);
 }

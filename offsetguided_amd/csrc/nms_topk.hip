@@ -116,6 +116,19 @@ __device__ __forceinline__ Px<VEC> hmax3(const Px<VEC> &v)
     return h;
 }
 
+// flip-test folded into the fused source (FUSED kernels only): `in` holds the stride-4 heat maps of [images | mirrored images]
+// (2N x C planes); plane (n, c) is merged on the fly with plane (N + n, kp_perm[c]) read right to left.  kp_perm null: no flip.
+struct FlipSrc {
+    const int32_t *kp_perm;
+    int N, C;
+};
+__device__ __forceinline__ const float *flip_partner(const FlipSrc &fs, const float *in, int plane, size_t plane_elems)
+{
+    if (!fs.kp_perm) return nullptr;
+    const int n = plane / fs.C, c = plane - n * fs.C;
+    return in + ((size_t)(fs.N + n) * fs.C + fs.kp_perm[c]) * plane_elems;
+}
+
 struct TileGeom {
     int plane_rows, plane_cols;  // H, W
     int r0, r1;                  // interior rows [r0, r1)
@@ -210,9 +223,11 @@ __device__ __forceinline__ Px<VEC> vmax3(const Px<VEC> &a, const Px<VEC> &b, con
 // panel has 58 interior lanes (3 halo lanes each side).  Rows/columns outside the image are 0.0
 // (F.pad), everything downstream is the same emit() as the streaming walker.
 //   lr: low-res plane (h x w); the band covers hi-res rows [r0, r1), r0 % 4 == 0.
+//   lrb: with flip-test, the plane of the MIRRORED image's partner channel (config.heatmap_hflip) or null: every source value is then
+//   (lr[y][x] + lrb[y][w-1-x]) / 2, exactly what og_flip_merge_f32 would have written (decoder/factory.py:104-106).
 template <int PF, class Emit, class End = NoHook>
-__device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, int h, int w, const TileGeom &g, int q,
-                                                 Emit &&emit, End &&iter_end = NoHook())
+__device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, const float *__restrict__ lrb, int h, int w,
+                                                 const TileGeom &g, int q, Emit &&emit, End &&iter_end = NoHook())
 {
     const int H = 4 * h;
     const int qc = min(max(q, 0), w - 1);       // index clamp == torch's tap clamp
@@ -222,7 +237,11 @@ __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, i
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wt[r][j] = og_cubic_w[r][j];
-    auto src = [&](int row) { return lr[(size_t)min(max(row, 0), h - 1) * w + qc]; };
+    auto src = [&](int row) {
+        const size_t ro = (size_t)min(max(row, 0), h - 1) * w;
+        const float v = lr[ro + qc];
+        return lrb ? (v + lrb[ro + (w - 1 - qc)]) / 2.f : v;      // (uniform branch)
+    };
     auto hires = [&](const OgRow4 &t0, const OgRow4 &t1, const OgRow4 &t2, const OgRow4 &t3, int phase, int Y) {
         Px<4> o;
         const bool ok = in_img && Y >= 0 && Y < H;
@@ -444,7 +463,8 @@ struct WaveSeg {
 template <bool NMS_MODE, bool FUSED, bool SC1 = false, class Emit>
 __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uint64_t *all,
                                             uint64_t *flt, uint64_t *s_bound, int *s_nf, int tid, int nthr,
-                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit)
+                                            const float *__restrict__ p, int H, int W, int k, int nlists, int t_sub, Emit &&emit,
+                                            const float *__restrict__ pb = nullptr)
 {
     const int n_all = nlists * k, lane = tid & 63;
     // All of a thread's keys are requested before the first one is used (one memory round trip, not one per key), and
@@ -496,7 +516,7 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
     if (NMS_MODE && t < k && tid < 64) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
         // zero (ties at 0.0 broken by index, like every other tie)
-        auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
+        auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, pb, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
         const long hw = (long)H * W;
         for (long base = 0; base < hw && t < k; base += 64) {
             const long i = base + lane;
@@ -526,7 +546,7 @@ __global__ void __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_pe
 band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
                  int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic, uint64_t magic,
                  int H, int W, int k, int cap, BandMap bm, int max_bands, int panel_strips, int total, int padded, int helper,
-                 int wl)
+                 int wl, FlipSrc fs)
 {
     // all LDS comes from the dynamic region (no static __shared__ in front of it: the base stays
     // 16-byte aligned for ds_read_b128): [2*nwaves key buffers | histogram | per-wave counts/slots | tau]
@@ -721,7 +741,7 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
     if (wave < nstream) {  // threshold refresh at the END of each iteration (see walk_panel)
         if constexpr (FUSED) {
             setup(0);
-            walk_panel_fused<PF>(src, H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
+            walk_panel_fused<PF>(src, flip_partner(fs, in, plane, (size_t)(H >> 2) * (W >> 2)), H >> 2, W >> 2, g, q_lane, emit_fn, iter_begin);
         } else {
             walk_panel<VEC, PF>(src, g, emit_fn, NoHook(), iter_begin, setup);
         }
@@ -788,7 +808,7 @@ template <bool NMS_MODE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
 merge_bands_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ hist_all, uint64_t *__restrict__ ws_magic,
                    uint64_t magic, const float *__restrict__ in, int H, int W, int k, BandMap bm, int max_bands, int wl, int t_sub,
-                   float *__restrict__ out_scores, int64_t *__restrict__ out_inds)
+                   float *__restrict__ out_scores, int64_t *__restrict__ out_inds, FlipSrc fs)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const int plane = blockIdx.x, tid = threadIdx.x;
@@ -803,7 +823,8 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ his
     merge_plane<NMS_MODE, FUSED>(band_keys + (size_t)first * wl * k, lds64, lds64 + (size_t)max_bands * wl * k,
                                  &s_bound, &s_nf, tid, 256,
                                  in + (FUSED ? (size_t)plane * (H >> 2) * (W >> 2) : (size_t)plane * H * W), H, W, k, nlists,
-                                 t_sub, [&](int rank, float v, long idx) { os[rank] = v; oi[rank] = (int64_t)idx; });
+                                 t_sub, [&](int rank, float v, long idx) { os[rank] = v; oi[rank] = (int64_t)idx; },
+                                 FUSED ? flip_partner(fs, in, plane, (size_t)(H >> 2) * (W >> 2)) : nullptr);
 }
 
 // Merge + K2 in one launch (the tail of og_generate_limbs_f32): workgroup (image, limb type) merges the limb's two joint
@@ -811,11 +832,13 @@ merge_bands_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ his
 // there (collect_body.h); behind them ceil(planes / 2) workgroups write the (N,C,k) lists the caller sees and clean the
 // workspace.  A plane is merged by every limb that uses it (2.2 times on the COCO skeleton): 4 KB of L2 reads each, against
 // a launch, a launch gap and a round trip of the lists through memory.
-template <int ND>
+// FUSED: `in` = the stride-4 heat maps (the zero-fill path of merge_plane evaluates the x4 bicubic at single points).
+template <int ND, bool FUSED = false>
 __global__ void __launch_bounds__(512)
 merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ hist_all,
                      uint64_t *__restrict__ ws_magic, uint64_t magic, const float *__restrict__ in, BandMap bm, int max_bands,
-                     int wl, int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL)
+                     int wl, int t_sub, float *__restrict__ out_scores, int64_t *__restrict__ out_inds, og_collect::Args a, int NL,
+                     FlipSrc fs)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint64_t s_bound[2];
@@ -846,12 +869,14 @@ merge_collect_kernel(const uint64_t *__restrict__ band_keys, int *__restrict__ h
     int *oi32 = li + half * Kp;
     int64_t *oi64 = out_inds + (size_t)plane * k;
     const int first = bm_start(bm, plane), nlists = (bm_start(bm, plane + 1) - first) * wl;
-    merge_plane<true, false>(band_keys + (size_t)first * wl * k, all, flt, &s_bound[half],
-                             &s_nf[half], tid, 256, in + (size_t)plane * H * W, H, W, k, nlists, t_sub,
+    const size_t plane_elems = FUSED ? (size_t)(H >> 2) * (W >> 2) : (size_t)H * W;
+    merge_plane<true, FUSED>(band_keys + (size_t)first * wl * k, all, flt, &s_bound[half],
+                             &s_nf[half], tid, 256, in + (size_t)plane * plane_elems, H, W, k, nlists, t_sub,
                              [&](int rank, float v, long idx) {
                                  if (limb) { os[rank] = v; oi32[rank] = (int)idx; }
                                  else if (live) { os[rank] = v; oi64[rank] = (int64_t)idx; }
-                             });
+                             },
+                             FUSED ? flip_partner(fs, in, plane, plane_elems) : nullptr);
     if (!limb) return;
     __syncthreads();
     MERGE_STAMP(1);
@@ -924,7 +949,8 @@ struct Pairing {   // og_generate_limbs_f32: the merge launch pairs the limbs as
 
 template <bool NMS_MODE, bool FUSED = false>
 int run_topk(const float *in, long planes, int H, int W, int k, float *out_scores, int64_t *out_inds,
-             void *workspace, size_t workspace_bytes, hipStream_t stream, const char *name, const Pairing *pair = nullptr)
+             void *workspace, size_t workspace_bytes, hipStream_t stream, const char *name, const Pairing *pair = nullptr,
+             FlipSrc fs = FlipSrc{nullptr, 0, 0})
 {
     OG_REQUIRE(in && out_scores && out_inds && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(planes > 0 && H > 0 && W > 0 && k > 0, OG_EINVAL, "%s: bad shape", name);
@@ -937,11 +963,14 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     int wl = p.wl, t_sub = p.t_sub;
     if (FUSED) {  // lanes are source columns (58 interior per wave); bands start on a source row (bm_row: multiples of 4)
         const int w4 = W / 4;
+        OG_REQUIRE((w4 + 57) / 58 < kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide", name, W);
+        const int plan_waves = p.nwaves;
         p.nwaves = (w4 + 57) / 58;
-        OG_REQUIRE(p.nwaves < kMaxWaves, OG_EUNSUPPORTED, "%s: W=%d too wide", name, W);
         p.panel_strips = (w4 + p.nwaves - 1) / p.nwaves;
-        wl = 1;   // (its wave count is not the plan's, which sized the workspace: one list per band)
-        t_sub = min(k, max(2, (k + p.bm.b_lo - 1) / p.bm.b_lo + 1));
+        if (p.nwaves != plan_waves) {   // (the plan sized the workspace for ITS wave count: one list per band then)
+            wl = 1;
+            t_sub = min(k, max(2, (k + p.bm.b_lo - 1) / p.bm.b_lo + 1));
+        }
     }
     OG_REQUIRE(workspace_bytes >= p.bytes, OG_ENOSPC, "%s: workspace %zu < %zu", name, workspace_bytes, p.bytes);
     OG_REQUIRE((uintptr_t)workspace % 8 == 0, OG_EINVAL, "%s: workspace must be 8-byte aligned", name);
@@ -958,34 +987,34 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     if (FUSED)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded,
-                           helper, wl);
+                           helper, wl, fs);
     else if (p.vec == 4)
         hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
-                           wl);
+                           wl, fs);
     else
         hipLaunchKernelGGL((band_topk_kernel<1, NMS_MODE, kPrefetch>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded, helper,
-                           wl);
+                           wl, fs);
     OG_LAUNCH_CHECK(name);
     // dynamic LDS the merge kernels may ask for without raising the 64 KiB default: their static __shared__ words (bounds,
     // counters: 24 B) come on top
     constexpr size_t kDynLdsLimit = 64 * 1024 - 256;
     const size_t mlds = (size_t)2 * p.max_bands * wl * k * sizeof(uint64_t);
     OG_REQUIRE(mlds <= kDynLdsLimit, OG_EUNSUPPORTED, "%s: k*bands too large for the merge stage", name);
-    if constexpr (NMS_MODE && !FUSED) {
+    if constexpr (NMS_MODE) {
         const size_t plds = 2 * mlds + (size_t)((k + 3) & ~3) * 32;
         if (pair && plds <= kDynLdsLimit) {
             const int NL = pair->N * pair->a.L;
-            auto kern = pair->nd == 2 ? merge_collect_kernel<2> : merge_collect_kernel<4>;
+            auto kern = pair->nd == 2 ? merge_collect_kernel<2, FUSED> : merge_collect_kernel<4, FUSED>;
             hipLaunchKernelGGL(kern, dim3((unsigned)(NL + (planes + 1) / 2)), dim3(512), plds, stream, keys, hist, magic,
-                               p.magic, in, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds, pair->a, NL);
+                               p.magic, in, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds, pair->a, NL, fs);
             OG_LAUNCH_CHECK(name);
             return 1;   // paired
         }
     }
     hipLaunchKernelGGL((merge_bands_kernel<NMS_MODE, FUSED>), dim3((unsigned)planes), dim3(256), mlds, stream, keys, hist,
-                       magic, p.magic, in, H, W, k, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds);
+                       magic, p.magic, in, H, W, k, p.bm, p.max_bands, wl, t_sub, out_scores, out_inds, fs);
     OG_LAUNCH_CHECK(name);
     return OG_OK;
 }
@@ -1067,12 +1096,15 @@ OG_API size_t og_generate_limbs_workspace_bytes(int N, int C, int H, int W, int 
     return two_step_bytes(N, C, H, W, k, true);
 }
 
+// hm_lowres: hmps_hr holds the STRIDE-4 heat maps (N [2N with kp_perm], C, H/4, W/4) and the x4 bicubic runs inside the band kernel
+// (K1-fused); kp_perm (with hm_lowres only): flip-test, the heat maps of [images | mirrored images] merged on the fly.
 static int generate_limbs_impl(const char *name, const float *hmps_hr, const float *offs, int off_is_lowres, int vector_nd,
                                const float *scales, int scales_mode, const float *jitter, int jitter_mode,
                                int N, int C, int H, int W, const int32_t *jf, const int32_t *jt, int L, int k,
                                float thre_hmp, float min_len, float resize_factor, float *topk_scores,
                                int64_t *topk_inds, float *limbs, const int32_t *limb_perm, const int32_t *reserve_mask,
-                               void *workspace, size_t workspace_bytes, void *stream)
+                               void *workspace, size_t workspace_bytes, void *stream, bool hm_lowres = false,
+                               const int32_t *kp_perm = nullptr)
 {
     OG_REQUIRE(hmps_hr && offs && jf && jt && limbs && workspace, OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE((topk_scores == nullptr) == (topk_inds == nullptr), OG_EINVAL, "%s: topk_scores and topk_inds go together", name);
@@ -1103,8 +1135,11 @@ static int generate_limbs_impl(const char *name, const float *hmps_hr, const flo
     int64_t *id = own_lists ? reinterpret_cast<int64_t *>(ws2 + topk) : topk_inds;
     const Pairing pr{ca, vector_nd, N};
     const bool can_pair = (long)H * W < (1l << 31) && k <= 2048;
-    const int rc = run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
-                                  can_pair ? &pr : nullptr);
+    OG_REQUIRE(!hm_lowres || (H % 4 == 0 && W % 4 == 0), OG_EINVAL, "%s: H,W must be multiples of 4", name);
+    const int rc = hm_lowres ? run_topk<true, true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
+                                                    can_pair ? &pr : nullptr, FlipSrc{kp_perm, N, C})
+                             : run_topk<true>(hmps_hr, (long)N * C, H, W, k, sc, id, ws2, topk, (hipStream_t)stream, name,
+                                              can_pair ? &pr : nullptr);
     if (rc < 0 || rc == 1) return rc < 0 ? rc : OG_OK;
     // (shapes whose merge + pairing stage does not fit the LDS: the lists are complete, pair them with the collect kernel)
     OG_REQUIRE(!limb_perm, OG_EUNSUPPORTED, "%s: k = %d is too large for the merge-and-pair stage of the flip-folded form", name, k);
@@ -1137,6 +1172,40 @@ OG_API int og_generate_limbs_flip_f32(const float *hmps_hr, const float *offs_pa
     return generate_limbs_impl(name, hmps_hr, offs_pair, 1, 2, nullptr, 0, nullptr, 0, N, C, H, W, jf, jt, L, k, thre_hmp, min_len,
                                resize_factor, topk_scores, topk_inds, limbs, limb_perm, reserve_mask, workspace, workspace_bytes,
                                stream);
+}
+
+// ---- K1-fused: generate_limbs straight from the STRIDE-4 head outputs.  The x4 bicubic of decoder/factory.py:74-75 runs inside the
+// band kernel (bit-identical to og_upsample_bicubic4_f32), the offsets / scale / jitter maps are sampled at the peaks: neither hi-res
+// tensor exists.  Two launches, as og_generate_limbs_f32.
+OG_API int og_generate_limbs_fused_f32(const float *hmps_lr, const float *offs_lr, int vector_nd, const float *scales_lr,
+                                       int scales_mode, const float *jitter_lr, int jitter_mode, int N, int C, int h, int w,
+                                       const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
+                                       float resize_factor, float *topk_scores, int64_t *topk_inds, float *limbs, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_generate_limbs_fused_f32";
+    OG_REQUIRE(h > 0 && w > 0 && h < (1 << 14) && w < (1 << 14), OG_EINVAL, "%s: bad shape", name);
+    OG_REQUIRE(scales_mode == 0 || scales_mode >= 2, OG_EINVAL, "%s: the scale maps are the stride-4 head output (scales_mode 2 / 3)", name);
+    OG_REQUIRE(jitter_mode == 0 || jitter_mode == 3, OG_EINVAL, "%s: the jitter maps are the stride-4 head output (jitter_mode 3)", name);
+    return generate_limbs_impl(name, hmps_lr, offs_lr, 1, vector_nd, scales_lr, scales_mode, jitter_lr, jitter_mode, N, C, 4 * h, 4 * w,
+                               jf, jt, L, k, thre_hmp, min_len, resize_factor, topk_scores, topk_inds, limbs, nullptr, nullptr, workspace,
+                               workspace_bytes, stream, true);
+}
+
+// ... with flip_augment (decoder/factory.py:98-146, the averaged form) folded into BOTH consumers: hm_pair_lr (2N,C,h,w) and
+// offs_pair_lr (2N,2L,h,w) are the head outputs for [images | mirrored images]; no merge pass, no hi-res tensor.
+OG_API int og_generate_limbs_fused_flip_f32(const float *hm_pair_lr, const int32_t *kp_perm, const float *offs_pair_lr,
+                                            const int32_t *limb_perm, const int32_t *reserve_mask, int N, int C, int h, int w,
+                                            const int32_t *jf, const int32_t *jt, int L, int k, float thre_hmp, float min_len,
+                                            float resize_factor, float *topk_scores, int64_t *topk_inds, float *limbs,
+                                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *name = "og_generate_limbs_fused_flip_f32";
+    OG_REQUIRE(kp_perm && limb_perm && reserve_mask, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(h > 0 && w > 0 && h < (1 << 14) && w < (1 << 14), OG_EINVAL, "%s: bad shape", name);
+    return generate_limbs_impl(name, hm_pair_lr, offs_pair_lr, 1, 2, nullptr, 0, nullptr, 0, N, C, 4 * h, 4 * w, jf, jt, L, k, thre_hmp,
+                               min_len, resize_factor, topk_scores, topk_inds, limbs, limb_perm, reserve_mask, workspace,
+                               workspace_bytes, stream, true, kp_perm);
 }
 
 #ifdef OG_K1_STAMPS

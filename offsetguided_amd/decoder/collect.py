@@ -20,8 +20,9 @@ class LimbsCollect(object):
     Keypoint-scale and jitter-offset heads (off in every published configuration) are supported:
     K2 samples the stride-4 maps at the peaks with the arithmetic of F.interpolate(x4).
 
-    On hi-res heatmaps the whole of generate_limbs -- NMS, top-k and the pairing -- is ONE C call
-    (og_generate_limbs_f32): two launches queued back to back (band top-k; merge + pairing).
+    The whole of generate_limbs -- NMS, top-k and the pairing -- is ONE C call: two launches queued back to back (band
+    top-k; merge + pairing), on hi-res heatmaps (og_generate_limbs_f32) or straight on the stride-4 head output with the x4
+    bicubic inside the band kernel (og_generate_limbs_fused_f32, the production path).
     """
 
     def __init__(self, hmp_s, off_s, *, topk=40, thre_hmp=0.08, min_len=3,
@@ -90,6 +91,28 @@ class LimbsCollect(object):
                 float(self.resize_factor), None, None, _lib.ptr(limbs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
         return limbs
 
+    def generate_limbs_fused_flip(self, hm_pair_lr, offs_pair_lr, kp_perm, limb_perm, reserve_mask):
+        """generate_limbs_fused on the flip-merged maps WITHOUT merging them first (og_generate_limbs_fused_flip_f32): the stride-4
+        head outputs of [images | mirrored images], (2N, C, h, w) and (2N, 2L, h, w); every heat-map source value and every offset tap
+        is computed as PostProcess.flip_augment would have written it (decoder/factory.py:98-146).  2-component offsets, no scale /
+        jitter head."""
+        hm = _lib.require_device(hm_pair_lr, 'hmps')
+        offs = _lib.require_device(offs_pair_lr, 'offs')
+        n2, c, h, w = hm.shape
+        n, n_limbs = n2 // 2, len(self.skeleton)
+        assert n2 == 2 * n and tuple(offs.shape) == (n2, 2 * n_limbs, h, w), 'head outputs of [images | mirrored images] at stride 4'
+        dev, lib = hm.device, _lib.load()
+        limbs = torch.empty((n, n_limbs, self.K, 13), dtype=torch.float32, device=dev)
+        jf, jt = _lib.int_table(self.jtypes_f, dev), _lib.int_table(self.jtypes_t, dev)
+        with _lib.stage_timer('k1f_fused_limbs', dev):
+            ws = _lib.workspace(dev, lib.og_generate_limbs_workspace_bytes(n, c, 4 * h, 4 * w, self.K), 'limbs')   # zero-filled
+            _lib.check(lib.og_generate_limbs_fused_flip_f32(
+                _lib.ptr(hm), _lib.ptr(_lib.int_table(kp_perm, dev)), _lib.ptr(offs), _lib.ptr(_lib.int_table(limb_perm, dev)),
+                _lib.ptr(_lib.int_table(reserve_mask, dev)), n, c, h, w, _lib.ptr(jf), _lib.ptr(jt), n_limbs, self.K,
+                float(self.thre_hmp), float(self.min_len), float(self.resize_factor), None, None, _lib.ptr(limbs), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr(dev)), lib)
+        return limbs
+
     def generate_limbs_fused(self, hmps_lr, offs_lr, vector_nd=2, scmps_lr=None, scale_inter='bicubic', jomps_lr=None):
         """Same limbs as generate_limbs(F.interpolate(hmps_lr, x4, 'bicubic'), [], F.interpolate(offs_lr, x4,
         'bilinear'), []) with NEITHER hi-res tensor built: K1-fused upsamples inside the NMS kernel."""
@@ -140,11 +163,11 @@ class LimbsCollect(object):
                     _lib.ptr(limbs), 0, _lib.ptr(ws), ws.numel(),
                     _lib.stream_ptr(dev)), lib)
                 return limbs
-            scores, inds = _topk_raw("og_upsample_nms_topk_f32", hmps_hr, self.K, scale=4)   # K1-fused: upsample inside
-            _lib.check(lib.og_collect_limbs_full_f32(
-                _lib.ptr(scores), _lib.ptr(inds), _lib.ptr(offs), int(off_is_lowres), int(vector_nd),
-                _lib.ptr(scales) if scales is not None else None, int(scales_mode),
-                _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h, w, _lib.ptr(jf), _lib.ptr(jt),
-                n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor),
-                _lib.ptr(limbs), _lib.stream_ptr(dev)), lib)
+            # K1-fused: the x4 bicubic runs inside the NMS kernel; ONE C call = two launches (band top-k; merge + pairing)
+            ws = _lib.workspace(dev, lib.og_generate_limbs_workspace_bytes(n, c, h, w, self.K), 'limbs')   # zero-filled
+            _lib.check(lib.og_generate_limbs_fused_f32(
+                _lib.ptr(hmps_hr), _lib.ptr(offs), int(vector_nd), _lib.ptr(scales) if scales is not None else None, int(scales_mode),
+                _lib.ptr(jitter) if jitter is not None else None, int(jitter_mode), n, c, h // 4, w // 4, _lib.ptr(jf), _lib.ptr(jt),
+                n_limbs, self.K, float(self.thre_hmp), float(self.min_len), float(self.resize_factor), None, None,
+                _lib.ptr(limbs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
         return limbs

@@ -354,16 +354,47 @@ def test_flip_fold_equals_flip_merge(dev, shape, headnet, topk):
     l_ref = proc.limb_collect.generate_limbs_lowres(hr_ref, mo)
     l_fold = proc.limb_collect.generate_limbs_flip(hr, t_off, limb_perm, keep)
     assert torch.equal(l_fold, l_ref)
+    # K1-fused with the merge folded into its source loads and its offset taps (og_generate_limbs_fused_flip_f32) == the same limbs
+    l_ffold = proc.limb_collect.generate_limbs_fused_flip(t_hm, t_off, kp_perm, limb_perm, keep)
+    assert torch.equal(l_ffold, l_ref)
+    l_fsep = proc.limb_collect.generate_limbs_fused(mh, mo)
+    assert torch.equal(l_fsep, l_ref)
     feats = [([None, t_hm], [[], []], [[], []]), ([None, t_off], [[], []], [[], []])]
-    poses_fold = proc.generate_poses(feats, flip_test=True)
-    proc.fold_flip = False
-    poses_ref = proc.generate_poses(feats, flip_test=True)
-    assert len(poses_fold) == len(poses_ref) == n and all(np.array_equal(a_, b_) for a_, b_ in zip(poses_fold, poses_ref))
+    for fused in (True, False):
+        proc.fused_upsample, proc.fold_flip = fused, True
+        poses_fold = proc.generate_poses(feats, flip_test=True)
+        proc.fold_flip = False
+        poses_ref = proc.generate_poses(feats, flip_test=True)
+        assert len(poses_fold) == len(poses_ref) == n and all(np.array_equal(a_, b_) for a_, b_ in zip(poses_fold, poses_ref))
     sel = [0, 1, n, n + 1]
     ref, _ = oracle.decode(hm[sel], off[sel], skel, topk_k=topk, thre_hmp=FLAGS["thre_hmp"],
                            min_len=FLAGS["min_len"], person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"],
                            flip=flip_tables(skel))
     assert_poses_match(ref, poses_fold[:2], SCORE_TOL)
+
+
+def test_fused_flip_fold_few_peaks(dev):
+    """The folded flip in K1-fused where a plane has FEWER than k positive peaks: the merge stage then fills the list with the lowest
+    zero-output indices, evaluating the x4 bicubic of the MERGED source at single points (merge_plane's zero-fill path with the
+    mirrored partner plane) -- bit-equal to og_flip_merge_f32 followed by the fused kernel, and to the oracle."""
+    n, h, w = 2, 96, 128
+    hm, off = synth.synth_batch(77, n, h, w, flip=True, n_persons=2)
+    hm[:, 3] = -np.abs(hm[:, 3])                   # a plane without positive values
+    hm[:, 5] = 0.0                                 # an all-zero plane
+    hm[:, 7] *= (np.abs(hm[:, 7]) > 0.3)           # a plane with one or two blobs and exact zeros elsewhere
+    t_hm, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+    proc = processor(n)
+    kp_perm, (limb_perm, reserve) = proc.keypoints_flips, proc.limbs_flips
+    keep = [1 if l in reserve else 0 for l in range(len(limb_perm))]
+    mh, _, mo, _, _ = proc.flip_augment(t_hm, [], t_off, [], False, 2)
+    l_sep = proc.limb_collect.generate_limbs_fused(mh, mo)
+    l_fold = proc.limb_collect.generate_limbs_fused_flip(t_hm, t_off, kp_perm, limb_perm, keep)
+    assert torch.equal(l_fold, l_sep)
+    l_hr = proc.limb_collect.generate_limbs_lowres(decoder.factory.upsample4(mh, 'bicubic'), mo)
+    assert torch.equal(l_fold, l_hr)
+    ref, _ = oracle.decode(hm, off, cd.COCO_PERSON_SKELETON, topk_k=FLAGS["topk"], thre_hmp=FLAGS["thre_hmp"], min_len=FLAGS["min_len"],
+                           person_thre=FLAGS["person_thre"], dist_max=FLAGS["dist_max"], flip=flip_tables())
+    assert_poses_match(ref, proc.generate_poses(features(hm, off, dev), flip_test=True), SCORE_TOL)
 
 
 @pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat", "pipe256_omp16_flipcat_p6", "pipe256_omp44_flipcat_p6"])
@@ -383,6 +414,8 @@ def test_generate_poses_golden(dev, name):
     """Drop-in surface: decoder_factory(args).generate_poses(features, flip_test) vs the reference's output."""
     g, hm, off = load_case(name)
     proc = case_processor(g)
+    assert proc.fused_upsample                       # the production default (K1-fused) is test_generate_poses_fused_golden's
+    proc.fused_upsample = False                      # here: K1a + K1 on the materialised hi-res maps (the reference's structure)
     feats = features(hm, off, dev)
     limbs = proc.generate_limbs(feats, flip_test=bool(g["flip"]), cat_flip_offs=is_cat(g)).cpu().numpy()
     assert_limbs_match(g["limbs"], limbs, SCORE_TOL)

@@ -9,7 +9,7 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd "$root"
 timeout 900 python bench.py > "$out/bench.json" 2> "$out/bench.err"
-bash tools/ab_env.sh "default:OG_X=0" "fused_upsample:OG_FUSED_UPSAMPLE=1" "default:OG_X=0" "fused_upsample:OG_FUSED_UPSAMPLE=1" > "$out/fused_upsample_ab.log" 2>&1
+bash tools/ab_env.sh "fused(default):OG_FUSED_UPSAMPLE=1" "k1a+k1:OG_FUSED_UPSAMPLE=0" "fused(default):OG_FUSED_UPSAMPLE=1" "k1a+k1:OG_FUSED_UPSAMPLE=0" "fused(default):OG_FUSED_UPSAMPLE=1" "k1a+k1:OG_FUSED_UPSAMPLE=0" > "$out/fused_upsample_ab.log" 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$out/bench_profiled.json" 2> "$out/bench_profiled.err"
 kt=$(ls "$out"/stats/*/*_kernel_trace.csv | head -1)
