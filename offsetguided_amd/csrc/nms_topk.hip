@@ -229,6 +229,7 @@ template <int PF, class Emit, class End = NoHook>
 __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, const float *__restrict__ lrb, int h, int w,
                                                  const TileGeom &g, int q, Emit &&emit, End &&iter_end = NoHook())
 {
+    typedef float v2f __attribute__((ext_vector_type(2)));
     const int H = 4 * h;
     const int qc = min(max(q, 0), w - 1);       // index clamp == torch's tap clamp
     const bool in_img = q >= 0 && q < w;        // lanes outside the image produce the zero padding
@@ -242,23 +243,39 @@ __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, c
         const float v = lr[ro + qc];
         return lrb ? (v + lrb[ro + (w - 1 - qc)]) / 2.f : v;      // (uniform branch)
     };
-    auto hires = [&](const OgRow4 &t0, const OgRow4 &t1, const OgRow4 &t2, const OgRow4 &t3, int phase, int Y) {
-        Px<4> o;
-        const bool ok = in_img && Y >= 0 && Y < H;
+    // x-pass of one source row.  Lanes left / right of the image get ZERO x-pass results -- four selects per SOURCE row instead of
+    // sixteen per-pixel ones behind the y-pass: the y-pass of zeros is (signed) zero, which is all the 3x3 maximum of an edge pixel
+    // needs from its padding (v == m holds for +-0 alike, and a lane outside the image never emits)
+    auto xpass = [&](float c) {
+        OgRow4 o = og_cubic_xpass(c, wt);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = og_cubic_chain(t0.p[x], t1.p[x], t2.p[x], t3.p[x], wt[phase]);
-            o.c[x] = ok ? v : 0.f;
+        for (int j = 0; j < 4; ++j) o.p[j] = in_img ? o.p[j] : 0.f;
+        return o;
+    };
+    // y-pass of one hi-res row, two pixels per packed instruction (v_pk_mul_f32 / v_pk_fma_f32): the same chain as og_cubic_chain,
+    // element for element (o = fma(t0,w0, fl(t1*w1)); o = fma(t2,w2,o); o = fma(t3,w3,o))
+    auto hires = [&](const OgRow4 &t0, const OgRow4 &t1, const OgRow4 &t2, const OgRow4 &t3, int phase) {
+        Px<4> o;
+#pragma unroll
+        for (int x = 0; x < 4; x += 2) {
+            const v2f a0 = {t0.p[x], t0.p[x + 1]}, a1 = {t1.p[x], t1.p[x + 1]}, a2 = {t2.p[x], t2.p[x + 1]}, a3 = {t3.p[x], t3.p[x + 1]};
+            const v2f w0 = {wt[phase][0], wt[phase][0]}, w1 = {wt[phase][1], wt[phase][1]}, w2 = {wt[phase][2], wt[phase][2]},
+                      w3 = {wt[phase][3], wt[phase][3]};
+            v2f r = __builtin_elementwise_fma(a0, w0, a1 * w1);
+            r = __builtin_elementwise_fma(a2, w2, r);
+            r = __builtin_elementwise_fma(a3, w3, r);
+            o.c[x] = r[0];
+            o.c[x + 1] = r[1];
         }
         return o;
     };
+    auto zero_row = [] { Px<4> z; z.c[0] = z.c[1] = z.c[2] = z.c[3] = 0.f; return z; };
     const int p0 = g.r0 >> 2, p1 = g.r1 >> 2;   // source rows of the band (r0, r1 are multiples of 4)
-    // x-pass of source rows p0-2 .. p0+1: enough for hi-res row r0-1 (= phase 3 of source row p0-1)
-    OgRow4 xa = og_cubic_xpass(src(p0 - 2), wt), xb = og_cubic_xpass(src(p0 - 1), wt), xc = og_cubic_xpass(src(p0), wt),
-           xe = og_cubic_xpass(src(p0 + 1), wt);
-    Px<4> hm_a = hmax3<4>(hires(xa, xb, xc, xe, 3, g.r0 - 1));
-    OgRow4 xf = og_cubic_xpass(src(p0 + 2), wt);   // window of p0 complete: rows p0-2 .. p0+2
-    Px<4> v_b = hires(xa, xb, xc, xe, 0, g.r0);
+    // x-pass of source rows p0-2 .. p0+1: enough for hi-res row r0-1 (= phase 3 of source row p0-1; row -1 is zero padding)
+    OgRow4 xa = xpass(src(p0 - 2)), xb = xpass(src(p0 - 1)), xc = xpass(src(p0)), xe = xpass(src(p0 + 1));
+    Px<4> hm_a = hmax3<4>(g.r0 > 0 ? hires(xa, xb, xc, xe, 3) : zero_row());
+    OgRow4 xf = xpass(src(p0 + 2));   // window of p0 complete: rows p0-2 .. p0+2
+    Px<4> v_b = hires(xa, xb, xc, xe, 0);
     Px<4> hm_b = hmax3<4>(v_b);
     float pre[PF];                                  // prefetched source values of rows p+3 .. p+2+PF
 #pragma unroll
@@ -267,17 +284,18 @@ __device__ __forceinline__ void walk_panel_fused(const float *__restrict__ lr, c
 #pragma unroll
         for (int ph = 1; ph <= 4; ++ph) {          // produce hi-res row 4p+ph, emit row 4p+ph-1
             Px<4> v_c;
-            if (ph == 1) v_c = hires(xa, xb, xc, xe, 1, 4 * p + 1);
-            else if (ph == 2) v_c = hires(xb, xc, xe, xf, 2, 4 * p + 2);
-            else if (ph == 3) v_c = hires(xb, xc, xe, xf, 3, 4 * p + 3);
+            if (ph == 1) v_c = hires(xa, xb, xc, xe, 1);
+            else if (ph == 2) v_c = hires(xb, xc, xe, xf, 2);
+            else if (ph == 3) v_c = hires(xb, xc, xe, xf, 3);
             else {                                  // first row of source row p+1: shift the window, x-pass of row p+3
                 const float nxt = pre[0];
 #pragma unroll
                 for (int u = 0; u + 1 < PF; ++u) pre[u] = pre[u + 1];
                 pre[PF - 1] = src(p + 3 + PF);
                 xa = xb; xb = xc; xc = xe; xe = xf;
-                xf = og_cubic_xpass(nxt, wt);
-                v_c = hires(xa, xb, xc, xe, 0, 4 * p + 4);
+                xf = xpass(nxt);
+                v_c = hires(xa, xb, xc, xe, 0);
+                if (4 * p + 4 >= H) v_c = zero_row();       // (uniform) the row below the image: zero padding
             }
             const Px<4> hm_c = hmax3<4>(v_c);
             emit(4 * p + ph - 1, v_b, hm_a, hm_b, hm_c);
@@ -452,7 +470,7 @@ struct WaveSeg {
 };
 
 // ABL (tuning harness only, -DOG_K1_BAND_ABL): 0 = product; 1 = compute the admission masks but never push; 3 = loads and
-// threshold ballots only.
+// threshold ballots only; 4 = the whole NMS test (row maximum, 3x3 maxima, peak masks) without the candidate handling.
 // FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
 // the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
 // One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
@@ -703,6 +721,13 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         // instructions per row keep the kernel HBM-bound when the chip clocks down behind the backbone.
         // (masks are built from ballots of plain compares and combined on the scalar side: a ballot of `a && b` is
         // lowered through a 0/1 VGPR -- v_cndmask + v_cmp_ne per component)
+        // the lane's LARGEST pixel against the threshold first: one compare and one branch per wave-row on the hot path (two max
+        // instructions instead of four compares, and none of the scalar mask arithmetic) -- a pixel passes iff the maximum does
+        if constexpr (VEC == 4 && (ABL == 0 || ABL == 4)) {
+            const float rm = og_max3(v.c[0], v.c[1], fmaxf(v.c[2], v.c[3]));
+            if (__builtin_amdgcn_ballot_w64(NMS_MODE ? (__builtin_bit_cast(int, rm) >= seg.lane_tau_bits) : (rm >= seg.lane_tau_f)) == 0ull)
+                return;
+        }
         uint64_t ge[VEC], any = 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -727,6 +752,10 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
             for (int j = 0; j < VEC; ++j) {
                 mj[j] = NMS_MODE ? (ge[j] & __builtin_amdgcn_ballot_w64(v.c[j] == m.c[j])) : ge[j];
                 many |= mj[j];
+            }
+            if (ABL == 4) {   // harness: the whole NMS test, no candidate handling
+                seg.cnt += (int)(many >> 63);
+                return;
             }
             if (many != 0ull) {
 #pragma unroll
@@ -985,7 +1014,7 @@ int run_topk(const float *in, long planes, int H, int W, int k, float *out_score
     const dim3 block(64 * (p.nwaves + (helper & 1)));
     const size_t lds = (size_t)(p.nwaves + (helper & 1)) * 2 * p.cap * sizeof(uint64_t) + (kHistBins + 2 * kMaxWaves + 4) * sizeof(int);
     if (FUSED)
-        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, 0, true>), dim3(padded), block, lds, stream, in, keys,
+        hipLaunchKernelGGL((band_topk_kernel<4, NMS_MODE, kPrefetch, kBandAbl, true>), dim3(padded), block, lds, stream, in, keys,
                            hist, magic, p.magic, H, W, k, p.cap, p.bm, p.max_bands, p.panel_strips, (int)total, padded,
                            helper, wl, fs);
     else if (p.vec == 4)

@@ -79,6 +79,7 @@ class EvalPreprocess:
         f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
         self._mean, self._std, self._fill = f3(mean), f3(std), f3(fill)
         self._stage, self._turn = [None, None, None], 0
+        self._pack_lock = __import__('threading').Lock()   # ONE pack at a time (see pack)
         self.copy_stream = torch.cuda.Stream(self.device)
 
     def _staging(self, nbytes):
@@ -92,9 +93,18 @@ class EvalPreprocess:
 
     def pack(self, images):
         """Host part of a batch: the images copied into one pinned staging buffer.  No device call except the wait for the buffer's
-        previous H2D copy; may run on a worker thread while the caller's thread feeds the device (one pack at a time)."""
+        previous H2D copy; may run on a worker thread while the caller's thread feeds the device.  Invariant: ONE pack at a time
+        (the staging ring and its turn counter are not synchronised) -- enforced: a second concurrent pack raises instead of racing."""
         sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
         total = sum(h * w * 3 for h, w in sizes)
+        if not self._pack_lock.acquire(blocking=False):
+            raise RuntimeError('EvalPreprocess.pack: another pack is in progress (one packer at a time: a worker thread OR the caller)')
+        try:
+            return self._pack_locked(images, sizes, total)
+        finally:
+            self._pack_lock.release()
+
+    def _pack_locked(self, images, sizes, total):
         stage = self._staging(total)
         o = 0
         stage_np = stage[0].numpy()                    # (a plain memcpy: torch's copy_ into the pinned buffer ran at 0.7 GB/s)

@@ -119,7 +119,7 @@ def main():
                                                      w, _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(limbs3), sp), lib)
 
         ok = True
-        for i in range(a.rotate if len(a.forms) == 2 else 0):
+        for i in range(a.rotate if set(a.forms) >= {'two', 'three'} else 0):
             three(i)
             two(i)
             torch.cuda.synchronize()
@@ -145,7 +145,12 @@ def main():
             t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e3
             return float(np.median(t)), float(t.min())
 
-        fns = {'two': two, 'three': three}
+        def fused(i):   # the production form: x4 bicubic inside the band kernel, merge + pairing in one launch (no hi-res tensor)
+            _lib.check(lib.og_generate_limbs_fused_f32(_lib.ptr(lrs[i % a.rotate]), _lib.ptr(t_off), 2, None, 0, None, 0, n, c, h // 4, w // 4,
+                                                       _lib.ptr(jf), _lib.ptr(jt), L, k, 0.04, 0.5, 1.0, _lib.ptr(sc2), _lib.ptr(ix2),
+                                                       _lib.ptr(limbs2), _lib.ptr(ws1), ws1.numel(), sp), lib)
+
+        fns = {'two': two, 'three': three, 'fused': fused}
         res = {f'{f} cold': timed(fns[f]) for f in a.forms}
         res.update({f'{f} after K1a': timed(fns[f], k1a) for f in a.forms})
         if a.burst:
