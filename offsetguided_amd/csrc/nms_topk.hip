@@ -470,7 +470,7 @@ struct WaveSeg {
 };
 
 // ABL (tuning harness only, -DOG_K1_BAND_ABL): 0 = product; 1 = compute the admission masks but never push; 3 = loads and
-// threshold ballots only; 4 = the whole NMS test (row maximum, 3x3 maxima, peak masks) without the candidate handling.
+// threshold ballots only; 4 = the whole NMS test (3x3 maxima, peak masks) without the candidate handling.
 // FUSED: `in` holds the stride-4 head output (planes x H/4 x W/4) and the hi-res rows are produced on
 // the fly (walk_panel_fused) instead of being read from a materialised (planes x H x W) tensor.
 // One plane's merge by `nthr` consecutive threads (tid = 0..nthr-1 within the group; every thread of the workgroup calls
@@ -721,13 +721,9 @@ band_topk_kernel(const float *__restrict__ in, uint64_t *__restrict__ band_keys,
         // instructions per row keep the kernel HBM-bound when the chip clocks down behind the backbone.
         // (masks are built from ballots of plain compares and combined on the scalar side: a ballot of `a && b` is
         // lowered through a 0/1 VGPR -- v_cndmask + v_cmp_ne per component)
-        // the lane's LARGEST pixel against the threshold first: one compare and one branch per wave-row on the hot path (two max
-        // instructions instead of four compares, and none of the scalar mask arithmetic) -- a pixel passes iff the maximum does
-        if constexpr (VEC == 4 && (ABL == 0 || ABL == 4)) {
-            const float rm = og_max3(v.c[0], v.c[1], fmaxf(v.c[2], v.c[3]));
-            if (__builtin_amdgcn_ballot_w64(NMS_MODE ? (__builtin_bit_cast(int, rm) >= seg.lane_tau_bits) : (rm >= seg.lane_tau_f)) == 0ull)
-                return;
-        }
+        // (Comparing the lane's row MAXIMUM first -- one compare and one branch per wave-row, the four compares only behind it -- was
+        // measured on the bench inputs, where most wave-rows hold a pixel above the threshold: 57.5 vs 55.3 us for K1, 54.5 vs 49.3 us
+        // for K1-fused, profiles/r05_k1_rowmax_ab.log: the extra instructions are paid on every row and save nothing.  Not kept.)
         uint64_t ge[VEC], any = 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
