@@ -133,10 +133,9 @@ class PostProcess(torch.nn.Module):
         self.limbs_flips = config.offset_hflip(keypoints, skeleton)
         self.worker_pool = None  # grouping runs on the device; kept as an attribute for API parity
         # True (default since round 5): K1-fused -- the x4 bicubic runs inside the NMS kernel, neither hi-res tensor of
-        # decoder/factory.py:74-88 is built (identical results, 16x less HBM traffic, 59 -> us instead of 104 us of kernels per bs8
-        # batch).  False / OG_FUSED_UPSAMPLE=0: K1a materialises the hi-res heatmaps and K1 streams them, the reference's
-        # structure and the HBM-roofline path.  True: K1-fused upsamples inside the NMS kernel
-        # (identical results, 16x less HBM traffic).
+        # decoder/factory.py:74-88 is built (identical results, 16x less HBM traffic, ~50 us instead of ~105 us per bs8 batch).
+        # False / OG_FUSED_UPSAMPLE=0: K1a materialises the hi-res heatmaps and K1 streams them -- the reference's structure and the
+        # HBM-roofline benchmark mode.
         self.fused_upsample = os.environ.get('OG_FUSED_UPSAMPLE', '1') != '0'
         # flip-test (2-component offsets, no scale / jitter head): flip_augment's merge rides on the loads of K1a and on the
         # offset sampling of K1 instead of running as its own pass (K0, og_flip_merge_f32); identical results
