@@ -533,23 +533,26 @@ __device__ __forceinline__ void merge_plane(const uint64_t *__restrict__ gk, uin
     int t = min(nf, k);
     if (NMS_MODE && t < k && tid < 64) {
         // fewer than k positive peaks: fill with the lowest flat indices whose NMS output is
-        // zero (ties at 0.0 broken by index, like every other tie)
+        // zero (ties at 0.0 broken by index, like every other tie).  One wave walks the plane in index order, 62 pixels per
+        // round (lanes 1..62; lanes 0 and 63 are halo): a lane evaluates its COLUMN of three pixels (rows y-1, y, y+1; outside the
+        // plane = the zero padding) and takes the neighbouring columns' maxima from the adjacent lanes -- three point
+        // evaluations per lane instead of nine (K1-fused: 48 source taps instead of 160 per lane and round: this path cost the
+        // fused merge launch 3 us on the bench inputs, where a quarter of the planes have fewer than k positive peaks)
         auto px = [&](int yy, int xx) { return FUSED ? og_bicubic4_at(p, pb, H >> 2, W >> 2, yy, xx) : p[(size_t)yy * W + xx]; };
         const long hw = (long)H * W;
-        for (long base = 0; base < hw && t < k; base += 64) {
-            const long i = base + lane;
-            bool zero = false;
-            if (i < hw) {
-                const int y = (int)(i / W), x = (int)(i % W);
-                const float v = px(y, x);
-                float m = (y == 0 || x == 0 || y == H - 1 || x == W - 1) ? 0.f : -INFINITY;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int yy = y + dy, xx = x + dx;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, px(yy, xx));
-                    }
-                zero = !(v == m && v != 0.f);
-            }
+        for (long base = 0; base < hw && t < k; base += 62) {
+            const long i = base + lane - 1;
+            const bool in = i >= 0 && i < hw;
+            const int y = in ? (int)(i / W) : 0, x = in ? (int)(i % W) : 0;
+            float c[3];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) c[dy + 1] = (in && y + dy >= 0 && y + dy < H) ? px(y + dy, x) : 0.f;
+            const float cm = og_max3(c[0], c[1], c[2]);
+            float left = og_from_lane_below(cm), right = og_from_lane_above(cm);
+            left = x == 0 ? 0.f : left;           // the lane below holds the LAST pixel of the row above: zero padding instead
+            right = x == W - 1 ? 0.f : right;
+            const float m = og_max3(left, cm, right), v = c[1];
+            const bool zero = in && lane >= 1 && lane <= 62 && !(v == m && v != 0.f);
             const uint64_t mask = __builtin_amdgcn_ballot_w64(zero);
             const int slot = t + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
             if (zero && slot < k) emit(slot, 0.f, i);
