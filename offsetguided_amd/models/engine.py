@@ -435,7 +435,7 @@ def _run(seq, x, after_first=None):
 
 class _Level:
     def __init__(self, m, dtype, fused, depth=0):
-        self.fused, self.depth, self._side = fused, depth, None
+        self.fused, self.depth, self._side = fused, depth, {}
         self.up1, self.low1, self.low3 = _seq(m.up1, dtype, fused), _seq(m.low1, dtype, fused), _seq(m.low3, dtype, fused)
         self.low2 = (_Level(m.low2, dtype, fused, depth + 1) if isinstance(m.low2, HourglassLevel)
                      else _seq(m.low2, dtype, fused))
@@ -451,14 +451,21 @@ class _Level:
     def __call__(self, x):
         if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
-            if self._side is None:
+            # side streams belong to the ENGINE that issues the work (the levels themselves are shared by the engines of one model,
+            # _shared_layers): two engines in flight must not serialise their branches on one stream
+            key = (x.device.index, _issuer.engine)
+            side = self._side.get(key)
+            if side is None:
                 if DEEP_SHARED and self.depth >= DEEP_SHARED:
-                    if getattr(_issuer, 'deep_side', None) is None or _issuer.deep_side[0] != (x.device.index, _issuer.engine):
-                        _issuer.deep_side = ((x.device.index, _issuer.engine), torch.cuda.Stream(x.device))
-                    self._side = _issuer.deep_side[1]
+                    if getattr(_issuer, 'deep_side', None) is None or _issuer.deep_side[0] != key:
+                        _issuer.deep_side = (key, torch.cuda.Stream(x.device))
+                    side = _issuer.deep_side[1]
                 else:
-                    self._side = torch.cuda.Stream(x.device)
-            side, box = self._side, {}
+                    side = torch.cuda.Stream(x.device)
+                if len(self._side) >= 8:        # engines come and go (evaluate.run_images keeps four per model): forget the oldest
+                    self._side.pop(next(iter(self._side)))
+                self._side[key] = side
+            box = {}
             trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST
             fork_ev = None
             if trunk_first:
