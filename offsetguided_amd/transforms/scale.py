@@ -120,16 +120,6 @@ class EvalPreprocess:
         T = self.long_edge
         stage, sizes, total = packed if packed is not None else self.pack(images)
         assert len(sizes) == len(images)
-        with torch.cuda.stream(self.copy_stream):
-            # allocated on the copy stream's pool: a block of the compute stream's pool may still be in use by kernels
-            # queued there (the host runs a batch ahead), and the copy stream does not wait for them
-            dev_raw = torch.empty(total, dtype=torch.uint8, device=self.device)
-            dev_raw.copy_(stage[0][:total], non_blocking=True)
-            stage[1] = torch.cuda.Event()
-            stage[1].record(self.copy_stream)
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_stream(self.copy_stream)
-        dev_raw.record_stream(cur)
         targets = [rescale_size(w, h, T, self.fixed_height) for h, w in sizes]
         if self.fixed_height:   # RightDownPad: up to the next multiple of max_stride (transforms/pad.py:100-103)
             up = lambda v: (v + self.max_stride - 1) // self.max_stride * self.max_stride  # noqa: E731
@@ -138,18 +128,33 @@ class EvalPreprocess:
             PH, PW = padded.pop()
         else:
             PH = PW = T
-        out = torch.empty((len(images), 3, PH, PW), dtype=torch.float32, device=self.device)
         metas, o = [], 0
-        for i, (h, w) in enumerate(sizes):
-            tw, th = targets[i]
-            ltrb = (C.c_int * 4)()
-            _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, PH, PW,
-                                                       int(self.fixed_height), self._mean, self._std, self._fill,
-                                                       _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
-            o += h * w * 3
-            meta, _ = rescale_meta(initial_meta(w, h, None if image_ids is None else image_ids[i]), None, w, h, tw, th)
-            meta['offset'] = meta['offset'] - np.array(ltrb[:2], np.float64)          # CenterPad, transforms/pad.py:28-31
-            meta['valid_area'][:2] += np.array(ltrb[:2], np.float64)
-            meta['width_height'] = np.array([PW, PH])
-            metas.append(meta)
+        # The whole input chain runs on the COPY stream, behind the H2D copy it depends on: the caller's stream is busy with the
+        # previous batch (the host runs a batch ahead), and eight small launches queued there sat between that batch's decoder and this
+        # batch's backbone (tools/harness_gaps.py: 185 us between the heads kernel and the next stem).  The caller's stream only waits
+        # for the finished tensor.  (Neutral on bench.py's harness figure, 1 267 vs 1 271 img/s: the host waits 4.7 of every 6.2 ms for
+        # the previous batch, tools/harness_host_times.py -- the pitch is the device's.)
+        with torch.cuda.stream(self.copy_stream):
+            # allocated on the copy stream's pool: a block of the compute stream's pool may still be in use by kernels
+            # queued there (the host runs a batch ahead), and the copy stream does not wait for them
+            dev_raw = torch.empty(total, dtype=torch.uint8, device=self.device)
+            dev_raw.copy_(stage[0][:total], non_blocking=True)
+            stage[1] = torch.cuda.Event()
+            stage[1].record(self.copy_stream)
+            out = torch.empty((len(images), 3, PH, PW), dtype=torch.float32, device=self.device)
+            for i, (h, w) in enumerate(sizes):
+                tw, th = targets[i]
+                ltrb = (C.c_int * 4)()
+                _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, PH, PW,
+                                                           int(self.fixed_height), self._mean, self._std, self._fill,
+                                                           _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
+                o += h * w * 3
+                meta, _ = rescale_meta(initial_meta(w, h, None if image_ids is None else image_ids[i]), None, w, h, tw, th)
+                meta['offset'] = meta['offset'] - np.array(ltrb[:2], np.float64)          # CenterPad, transforms/pad.py:28-31
+                meta['valid_area'][:2] += np.array(ltrb[:2], np.float64)
+                meta['width_height'] = np.array([PW, PH])
+                metas.append(meta)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.copy_stream)
+        out.record_stream(cur)
         return out, metas
