@@ -624,16 +624,20 @@ def harness_block(a, model, dev, n_batches=24, warm=6):
     marks = {}
 
     def loader():
-        for b in range(n_batches + warm):
-            if b == warm:          # run_images reads ONE batch ahead: batch `warm` is requested (and then packed) right before batch
-                torch.cuda.synchronize(dev)   # warm - 1 is processed.  The clock starts here: the pack AND the processing of every counted batch
-                marks['t0'] = time.perf_counter()   # are inside the region; so is the processing of batch warm - 1, which is NOT counted (conservative)
+        # run_images reads ONE batch ahead: batch b is requested (and its pack starts on the worker) right before batch b - 1 is
+        # processed.  The clock runs from the request of batch `warm` to the request of batch `warm + n_batches`, the device drained at
+        # both ends: exactly n_batches packs (warm .. warm + n - 1) and exactly n_batches batches processed from start to finish
+        # (warm - 1 .. warm + n - 2) lie inside, plus one refill of the pipeline.  One more batch follows so that the last request exists.
+        for b in range(n_batches + warm + 1):
+            if b == warm or b == warm + n_batches:
+                torch.cuda.synchronize(dev)
+                marks['t0' if b == warm else 't1'] = time.perf_counter()
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
             yield imgs, [None] * a.batch, [{'image_id': b * a.batch + i} for i in range(a.batch)]
     results, ids = evaluate.run_images(args, loader(), model=model)
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - marks['t0']
-    assert len(ids) == (n_batches + warm) * a.batch
+    dt = marks['t1'] - marks['t0']
+    assert len(ids) == (n_batches + warm + 1) * a.batch
     return {'value': round(n_batches * a.batch / dt, 2), 'unit': 'images/sec', 'batches': n_batches,
             'ms_per_batch': round(dt / n_batches * 1e3, 3),
             'input': f'{a.batch} raw (h, w, 3) uint8 RGB host images per batch, eight COCO-like sizes (333x500 ... 640x640), pageable memory',
