@@ -596,6 +596,7 @@ def _shared_layers(model, dtype, device, stage, fused):
         hit = (weakref.ref(model), _Layers(model, dtype, device, stage, fused))
         while len(_layer_cache) >= _LAYER_CACHE_MAX:
             _layer_cache.pop(next(iter(_layer_cache)))
+        weakref.finalize(model, _layer_cache.pop, key, None)     # the folded weights (~0.75 GB) go when the module goes
     _layer_cache[key] = hit      # (re-)inserted last: most recently used
     return hit[1]
 
