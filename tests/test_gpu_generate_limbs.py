@@ -203,11 +203,10 @@ def test_random_shapes_all_forms_agree(dev):
     assert done >= 30
 
 
-@pytest.mark.parametrize("knobs", [{"OG_K1_BAND_WGS_PER_CU": "-1"}, {"OG_K1_BAND_WGS_PER_CU": "5"}, {"OG_K1_WAVE_LISTS": "0"}])
+@pytest.mark.parametrize("knobs", [{"OG_K1_WAVE_LISTS": "0"}, {"OG_NMS_ROWS": "48"}])
 def test_band_layout_knobs(dev, knobs):
-    """The kept A/B layouts of the band kernel (read once per process): balanced work-item map (planes cut into b or b+1
-    bands, a multiple of the CU count), one list per band instead of one per streaming wave -- the random-shape and the
-    full-size tests again in a child process, bit for bit against the separate entry points."""
+    """The kept A/B layouts of the band kernel (read once per process): one list per band instead of one per streaming wave, another
+    band height -- the random-shape and the full-size tests again in a child process, bit for bit against the separate entry points."""
     import os
     import subprocess
     import sys
