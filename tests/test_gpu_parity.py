@@ -397,6 +397,38 @@ def test_fused_flip_fold_few_peaks(dev):
     assert_poses_match(ref, proc.generate_poses(features(hm, off, dev), flip_test=True), SCORE_TOL)
 
 
+def test_decoder_forms_fuzz(dev):
+    """The four ways through the limb stage with flip-test -- K0 pass + K1a + K1, the flip folded into K1a / K1, K0 pass + K1-fused, the
+    flip folded into K1-fused (production) -- on 100 random configurations (batch, non-square sizes, k, every skeleton; planes without
+    positive values, exact zeros with few peaks, thousands of peaks): bit-identical limbs, every column."""
+    rng = np.random.default_rng(123)
+    done = 0
+    for it in range(100):
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 60)) * 4, int(rng.integers(8, 90)) * 4
+        k, headnet = int(rng.choice([1, 7, 20, 32, 48])), str(rng.choice(['omp', 'omp16', 'omp31', 'omp44', 'omp25']))
+        if k > 2 * (h + w) - 4:
+            continue
+        proc = processor(n, headnet, topk=k)
+        hm, off = synth.synth_batch(int(rng.integers(1 << 30)), n, h, w, flip=True, n_persons=int(rng.integers(0, 6)), skeleton=proc.skeleton)
+        mode = it % 4
+        if mode == 1:
+            hm[:, ::3] = -np.abs(hm[:, ::3])
+        elif mode == 2:
+            hm *= (np.abs(hm) > 0.25)
+        elif mode == 3:
+            hm += rng.normal(0, 0.2, hm.shape).astype(np.float32)
+        t_hm, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+        kp, (lp, rs) = proc.keypoints_flips, proc.limbs_flips
+        keep = [1 if l in rs else 0 for l in range(len(lp))]
+        mh, _, mo, _, _ = proc.flip_augment(t_hm, [], t_off, [], False, 2)
+        ref = proc.limb_collect.generate_limbs_lowres(decoder.factory.upsample4(mh, 'bicubic'), mo)
+        assert torch.equal(ref, proc.limb_collect.generate_limbs_fused(mh, mo)), (it, n, h, w, k, headnet, mode, 'K0 + K1-fused')
+        assert torch.equal(ref, proc.limb_collect.generate_limbs_fused_flip(t_hm, t_off, kp, lp, keep)), (it, n, h, w, k, headnet, mode, 'folded K1-fused')
+        assert torch.equal(ref, proc.limb_collect.generate_limbs_flip(decoder.factory.upsample4_flip(t_hm, kp), t_off, lp, keep)), (it, 'folded K1a / K1')
+        done += 1
+    assert done >= 80
+
+
 @pytest.mark.parametrize("name", ["pipe256_flipcat_p6", "pipe640_flipcat", "pipe256_omp16_flipcat_p6", "pipe256_omp44_flipcat_p6"])
 def test_collect_limbs_4d_offsets_hires_form(dev, name):
     """The reference's own call (collect.py:62 with vector_nd=4 on materialised hi-res offsets) == low-res sampling."""
