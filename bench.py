@@ -630,6 +630,9 @@ def harness_block(a, model, dev, n_batches=24, warm=6):
         # (warm - 1 .. warm + n - 2) lie inside, plus one refill of the pipeline.  One more batch follows so that the last request exists.
         for b in range(n_batches + warm + 1):
             if b == warm or b == warm + n_batches:
+                if b == warm:
+                    import gc
+                    gc.collect()       # the engine build of the warm-up batches leaves garbage: its collection belongs there, not in the region
                 torch.cuda.synchronize(dev)
                 marks['t0' if b == warm else 't1'] = time.perf_counter()
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
