@@ -332,6 +332,12 @@ int og_conv_band_f16(const void *x, const void *w_packed, const float *bias, con
  *     with k in its natural order (for og_conv1x1_tiled_* / og_conv1x1_heads_*).
  *   og_conv3x3_tiled_bf16: x (N,H,W,Cin), skip / out (N,H,W,Cout), bias fp32[Cout]; replaces convolution.forward
  *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
+/* Optional hint for the NEXT og_conv3x3_tiled_* / og_conv3x3_tiled_up2_* / og_conv_band_* launch issued by this host thread (taken and
+ * cleared by it): [w_next, w_next + bytes) = the packed weights of the layer that will run AFTER that launch.  The launch's
+ * workgroups touch those lines at entry (values unused), so that the next layer of a dependent chain -- the 20x20 / 10x10 / 5x5 levels,
+ * whose layers are bound by the latency of first-touch weight reads -- finds its weights in the memory-side cache instead of HBM.
+ * Purely a performance hint: results do not depend on it; NULL / 0 clears it. */
+void og_conv_next_weights_hint(const void *w_next, size_t bytes);
 int og_conv3x3_tiled_supported(int N, int H, int W, int Cin, int Cout);
 int og_conv3x3_pack_w16(const void *w, int Cin, int Cout, int order, void *packed, void *stream);
 size_t og_conv3x3_tiled_workspace_bytes(int N, int H, int W, int Cin, int Cout);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "og_conv1x1_heads_bf16": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "og_conv3x3s2_tiled_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "og_conv3x3_tiled_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "og_conv_next_weights_hint": (None, [_vp, _sz]),
     "og_conv3x3_tiled_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv3x3_tiled_up2_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_encode_heatmaps_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),

@@ -65,6 +65,7 @@ struct ConvArgs {
     uint32_t magic_w, magic_h, magic_chunks;   // ceil(2^32 / d) for d = W, H, Cin/64 (0 when d == 1): q = umulhi(n, magic)
     int x_bytes, w_bytes;        // tensor sizes for the buffer descriptors of the tiled kernels
     unsigned long long *stamps;  // debug: [workgroup][8] s_memrealtime (100 MHz) marks, or null
+    OgWarm warm;                 // tiled kernels: the next layer's weights to touch at entry, or {null, 0}
 };
 
 // diagnostic builds only (tools/build_variants.sh conv3x3.hip stamps "-DOG_DEBUG_STAMPS"; -DOG_TILED_STAMPS / -DOG_PW_STAMPS imply it):
@@ -230,6 +231,7 @@ conv3x3_kernel(ConvArgs a)
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: an SGPR
+    const unsigned warm_v = og_warm_touch(a.warm, (blockIdx.y * gridDim.x + blockIdx.x) * 256u + (unsigned)tid);   // the next layer's weights (sunk at the end)
     CONV_STAMP(0);
     const int m_tile = blockIdx.x / a.n_tiles, n_tile = blockIdx.x % a.n_tiles, split = blockIdx.y;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -437,6 +439,7 @@ conv3x3_kernel(ConvArgs a)
         epilogue_store<BM, BN>(acc, a, m0, n0, wave, lane);
     }
     CONV_STAMP(5);
+    og_warm_sink(warm_v);
 }
 
 struct Plan {
@@ -601,6 +604,7 @@ static int conv_run(const char *name, const void *x, const void *w, const float 
     a.w_row = taps * Cin + a.Cin2;
     auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); };
     a.magic_w = magic((uint32_t)W); a.magic_h = magic((uint32_t)H); a.magic_chunks = magic((uint32_t)(Cin / 64));
+    a.warm = og_take_warm_hint();
     a.stamps = g_stamps;
     a.n_tiles = p.n_tiles; a.steps_per_split = p.steps_per_split; a.ksplit = p.ksplit; a.relu = relu;
     const dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)p.ksplit);
@@ -695,6 +699,7 @@ namespace {
 int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, const float *bias, const void *skip, void *out, void *up,
                        int N, int H, int W, int Cin, int Cout, int relu, void *workspace, size_t workspace_bytes, void *stream)
 {
+    const OgWarm warm = og_take_warm_hint();      // (taken even when the launch is refused: a hint never outlives its call)
     OG_REQUIRE(x && w_packed && bias && (out || up), OG_EINVAL, "%s: null pointer", name);
     OG_REQUIRE(!up || (uintptr_t)up % 16 == 0, OG_EINVAL, "%s: `up` must be 16-byte aligned", name);
     OG_REQUIRE(N > 0 && H > 0 && W > 0, OG_EINVAL, "%s: bad shape", name);
@@ -714,6 +719,7 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
     h.stamps = g_stamps;
 #endif
     hipStream_t st = (hipStream_t)stream;
+    h.warm = warm;
     const long items = tiled_items(kind, N, H, W, Cout);
     h.ksplit = (items <= (long)kMaxTiles) ? tiled_ksplit(kind, items, Cin) : 1;
     if (h.ksplit > 1) {
@@ -785,6 +791,7 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
                "%s: needs Cout %% 128 == 0, Cin %% 64 == 0 and an output of 8k x 16k pixels or 2k x 40 (got %dx%d -> %dx%d, %d -> %d)", name,
                Hin, Win, H, W, Cin, Cout);
     ConvArgs h = {};
+    h.warm = og_take_warm_hint();
     h.x = (const unsigned short *)x; h.w = (const unsigned short *)w_packed; h.bias = bias;
     h.skip = (const unsigned short *)skip; h.out = (unsigned short *)out;
     h.N = N; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.M = (int)M; h.n_tiles = Cout / 128; h.relu = relu;

@@ -54,6 +54,7 @@ struct BandLayer {
     int w_bytes;
     int kw, kw2;                 // 32-channel chunks per wave: ceil(Cin / 32 / 4), ceil(Cin2 / 32 / 4)
     uint32_t magic_p;            // ceil(2^32 / (Win + 1))
+    OgWarm warm;                 // the next layer's weights to touch at entry (og_conv_next_weights_hint), or {null, 0}
 };
 
 #ifdef OG_BAND_STAMPS   // tuning builds only (tools/build_variants.sh conv_band.hip stamps -DOG_BAND_STAMPS, tools/band_stamps.py)
@@ -329,6 +330,7 @@ __global__ void __launch_bounds__(kWaves * 64)
 conv_band_kernel(BandLayer a, unsigned long long *stamps)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const unsigned warm_v = og_warm_touch(a.warm, blockIdx.x * (unsigned)(kWaves * 64) + threadIdx.x);   // first in the wave's queue
     const int wid = og_xcd_remap(blockIdx.x, gridDim.x);   // grid: a multiple of 8; consecutive work ids share an XCD
     if (wid >= a.total) return;
     const int items = a.N * a.bands;
@@ -336,6 +338,7 @@ conv_band_kernel(BandLayer a, unsigned long long *stamps)
     u32x4 wf[KW][9], wp[KW2 > 0 ? KW2 : 1];
     band_load_weights<KW, KW2>(a, g, wf, wp);
     band_role<PT, KW, KW2>(a, g, wid - g * items, wf, wp, lds, stamps ? stamps + (size_t)blockIdx.x * 8 : nullptr);
+    og_warm_sink(warm_v);
 }
 
 // OHWI weights (the memory order of a channels_last (Cout,Cin,3,3) tensor) [+ the projection's (Cout,Cin2)] -> fragment order:
@@ -501,8 +504,10 @@ OG_API int OG_LP_NAME(og_conv_band)(const void *x, const void *w_packed, const f
     const BandDesc d = {x, w_packed, bias, skip, x2, out, N, Hin, Win, Cin, Cout, stride, relu, H2, W2, Cin2, stride2};
     BandLayer a;
     BandPlan p;
+    const OgWarm warm = og_take_warm_hint();      // (taken even when the launch is refused: a hint never outlives its call)
     const int rc = fill_layer(name, a, p, d);
     if (rc != OG_OK) return rc;
+    a.warm = warm;
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *stamps = nullptr;
 #ifdef OG_BAND_STAMPS

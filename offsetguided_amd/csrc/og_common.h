@@ -27,6 +27,26 @@ void og_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
         }                                                                          \
     } while (0)
 
+// "Warm the next layer's weights" hint (og_conv_next_weights_hint, abi.cpp): set by the caller right before a convolution launch,
+// taken (and cleared) by that launch.  The kernel's workgroups touch one 128-byte line each of [ptr, ptr + bytes) at entry -- loads whose
+// values are not used: they pull the NEXT layer's weights from HBM into the memory-side cache while THIS layer computes.
+struct OgWarm {
+    const void *ptr;
+    unsigned bytes;
+};
+OgWarm og_take_warm_hint();
+
+// Device side: thread `gtid` of the launch touches line `gtid` of the region (a launch has more threads than the region has lines: one
+// load per thread at most).  The loads are the OLDEST vector-memory operations of their wave: every counted wait behind them covers
+// them; the value is kept alive until the end of the kernel by og_warm_sink.
+__device__ __forceinline__ unsigned og_warm_touch(const OgWarm &w, unsigned gtid)
+{
+    unsigned v = 0;
+    if (w.ptr && gtid < (w.bytes >> 7)) v = reinterpret_cast<const unsigned *>(w.ptr)[(size_t)gtid * 32];
+    return v;
+}
+__device__ __forceinline__ void og_warm_sink(unsigned v) { asm volatile("" ::"v"(v)); }
+
 // Compute units of the current device (256 on MI355X; 256 when the query fails), asked once per process and device.
 static inline int og_cu_count()
 {

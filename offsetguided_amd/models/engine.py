@@ -105,6 +105,10 @@ TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
 # first, so the 20x20 branch of depth 3 -- ready when the trunk enters depth 3 -- only starts behind the 10x10 branch of depth 4
 # and the trunk waits for it at the depth-3 merge.  A/B over three runs: 6.02 -> 5.95 ms with the band kernel, D = 2 / 4 lose.
 DEEP_SHARED = int(os.environ.get('OG_ENGINE_DEEP_SHARED', '3'))
+# OG_CONV_WARM_NEXT (default 1): a tiled / band convolution launch is told where the NEXT layer's packed weights lie
+# (og_conv_next_weights_hint) and touches them at entry: the layers of the 20x20 / 10x10 / 5x5 levels are bound by first-touch weight
+# reads from HBM (the big layers of the same forward have flushed the memory-side cache: 26 us cold vs 19.7 us warm for a 20x20 layer)
+CONV_WARM_NEXT = int(os.environ.get('OG_CONV_WARM_NEXT', '1'))
 CONV_UP2 = int(os.environ.get('OG_CONV_UP2', '1'))   # the hourglass merge (upsample x2 + add) on the epilogue of the convolution below it
 _conv_ws = {}
 _WHATIF = set(filter(None, os.environ.get('OG_ENGINE_WHATIF', '').split(',')))
@@ -142,6 +146,8 @@ class _Conv:
         self.stride, self.pad, self.relu = conv.stride, conv.padding, relu
         self.w_tiled = None          # weights in og_conv3x3_tiled_*'s layout, made on first use
         self.w_band = None           # weights (+ projection) in og_conv_band_*'s fragment order, made on first use
+        self.next_conv = None        # the layer that runs after this one in its chain (set by _link): whose weights to warm
+        self.w_alt = None            # conv2 of a projection block on the split-K kernel reads [w | projection] (_Residual.w_cat)
         self.fused = fused and w.shape[0] % 8 == 0
         strides = ((1, 1), (2, 2))
         self.hip3x3 = (self.fused and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) in strides
@@ -248,6 +254,7 @@ class _Conv:
             st2 = proj.stride[0]
         out = torch.empty((n, cout, (h - 1) // st + 1, (w - 1) // st + 1), dtype=x.dtype, device=x.device,
                           memory_format=torch.channels_last)
+        self.warm_next(lib)
         _lib.check(_lib.lp(lib, 'og_conv_band', x.dtype)(
             _lib.ptr(x), _lib.ptr(self.w_band), _lib.ptr(self.b32), _lib.ptr(skip) if skip is not None else None,
             _lib.ptr(x2) if proj is not None else None, _lib.ptr(out), n, h, w, c, cout, st, int(self.relu), h2, w2_, c2, st2,
@@ -302,6 +309,7 @@ class _Conv:
             self.w_tiled = torch.empty(self.w.numel(), dtype=self.w.dtype, device=self.w.device)
             _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 1, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
         out = torch.empty((n, cout, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        self.warm_next(lib)
         _lib.check(_lib.lp(lib, 'og_conv3x3s2_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
                                                              _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c,
                                                              cout, int(self.relu), _lib.stream_ptr(x.device)), lib)
@@ -314,6 +322,15 @@ class _Conv:
                 and self.w.shape[0] % 128 == 0 and not _WHATIF and x.is_cuda
                 and n * h * w * 4 * self.w.shape[0] < 2 ** 30        # the (N, Cout, 2H, 2W) tensor it updates in place
                 and _lib.load().og_conv3x3_tiled_supported(n, h, w, c, self.w.shape[0]))
+
+    def warm_next(self, lib):
+        """og_conv_next_weights_hint for the launch that follows: the packed weights of the layer after this one, in whichever layout
+        that layer has been run with (none yet during the first warm-up pass: its raw weights then)."""
+        nxt = self.next_conv
+        if not CONV_WARM_NEXT or nxt is None:
+            return
+        t = nxt.w_band if nxt.w_band is not None else (nxt.w_tiled if nxt.w_tiled is not None else (nxt.w_alt if nxt.w_alt is not None else nxt.w))
+        lib.og_conv_next_weights_hint(_lib.ptr(t), t.numel() * t.element_size())
 
     def up2(self, x, skip, up):
         """up += nearest_x2(act(conv(x) + bias + skip)) in one launch (up: (N, Cout, 2H, 2W) channels-last, in place)."""
@@ -332,6 +349,7 @@ class _Conv:
             _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 0, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
         need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, cout)
         ws = _conv3x3_workspace(x.device, need) if need else None
+        self.warm_next(lib)
         _lib.check(_lib.lp(lib, 'og_conv3x3_tiled_up2', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
                                                                  _lib.ptr(skip) if skip is not None else None, _lib.ptr(up), n, h, w,
                                                                  c, cout, int(self.relu), _lib.ptr(ws) if need else None,
@@ -355,12 +373,14 @@ class _Conv:
                 _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(self.w), c, cout, 0, _lib.ptr(self.w_tiled), _lib.stream_ptr(x.device)), lib)
             need = lib.og_conv3x3_tiled_workspace_bytes(n, h, w, c, cout)      # K-split levels: tickets + fp32 slabs
             ws = _conv3x3_workspace(x.device, need) if need else None
+            self.warm_next(lib)
             _lib.check(_lib.lp(lib, 'og_conv3x3_tiled', x.dtype)(_lib.ptr(x), _lib.ptr(self.w_tiled), _lib.ptr(self.b32),
                                                                _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w,
                                                                c, cout, int(self.relu), _lib.ptr(ws) if need else None,
                                                                ws.numel() if need else 0, _lib.stream_ptr(x.device)), lib)
             return out
         ws = _conv3x3_workspace(x.device, lib.og_conv2d_workspace_bytes(n, h, w, c, cout, 3, st))
+        self.warm_next(lib)
         _lib.check(_lib.lp(lib, 'og_conv2d', x.dtype)(_lib.ptr(x), _lib.ptr(self.w), _lib.ptr(self.b32),
                                       _lib.ptr(skip) if skip is not None else None, _lib.ptr(out), n, h, w, c, cout, 3, st,
                                       int(self.relu), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)), lib)
@@ -383,6 +403,7 @@ class _Residual:
                 cout = self.c2.w.shape[0]
                 self.w_cat = torch.cat([self.c2.w.permute(0, 2, 3, 1).reshape(cout, -1),
                                         self.skip.w.reshape(cout, -1)], 1).contiguous()
+                self.c2.w_alt = self.w_cat
 
     def __call__(self, x, merge_up=None, after_c1=None):
         """-> the block's output; with `merge_up` (the up1 tensor of the hourglass level above, channels-last) and conv2 on
@@ -415,6 +436,7 @@ class _Residual:
         lib = _lib.load()
         out = torch.empty((n, cout, h, w), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
         ws = _conv3x3_workspace(y.device, lib.og_conv2d_proj_workspace_bytes(n, h, w, c, cout, 3, 1, c2))
+        self.c2.warm_next(lib)
         _lib.check(_lib.lp(lib, 'og_conv2d_proj', y.dtype)(_lib.ptr(y), _lib.ptr(self.w_cat), _lib.ptr(self.c2.b32), _lib.ptr(x), _lib.ptr(out),
                                            n, h, w, c, cout, 3, 1, h2, w2, c2, st2, 1, _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr(y.device)), lib)
@@ -423,6 +445,14 @@ class _Residual:
 
 def _seq(mods, dtype, fused):
     return [_Residual(m, dtype, fused) for m in mods]
+
+
+def _link(blocks):
+    """Successor links along a chain of residual blocks (conv1 -> conv2 -> the next block's conv1): _Conv.next_conv."""
+    for i, r in enumerate(blocks):
+        r.c1.next_conv = r.c2
+        if i + 1 < len(blocks):
+            r.c2.next_conv = blocks[i + 1].c1
 
 
 def _run(seq, x, after_first=None):
@@ -439,6 +469,15 @@ class _Level:
         self.up1, self.low1, self.low3 = _seq(m.up1, dtype, fused), _seq(m.low1, dtype, fused), _seq(m.low3, dtype, fused)
         self.low2 = (_Level(m.low2, dtype, fused, depth + 1) if isinstance(m.low2, HourglassLevel)
                      else _seq(m.low2, dtype, fused))
+        # the trunk's chain through this level (the up1 branch is its own chain): low1 -> [low2 ...] -> low3
+        _link(self.up1)
+        if isinstance(self.low2, _Level):
+            _link(self.low1)
+            _link(self.low3)
+            self.low1[-1].c2.next_conv = self.low2.low1[0].c1
+            self.low2.low3[-1].c2.next_conv = self.low3[0].c1
+        else:
+            _link(self.low1 + self.low2 + self.low3)
 
     def _lower(self, x, after_first=None):
         """-> the input of low3's LAST residual (that one runs after the join: the merge may ride on its epilogue)"""
