@@ -142,7 +142,7 @@ class PostProcess(torch.nn.Module):
         self.fold_flip = os.environ.get('OG_FOLD_FLIP', '1') != '0'
         # submit(): grouping (one workgroup per image, latency-bound) and the pose D2H copy run on their own stream, so
         # the caller's next launches (the following batch's backbone) do not queue behind them
-        self.group_on_side_stream = os.environ.get('OG_GROUP_SIDE_STREAM', '1') != '0'
+        self.group_on_side_stream = True   # (an attribute, no longer an environment switch: measured best since round 2)
         self._side = {}
         self._pinned = {}   # (poses shape, meta shape) -> [_HostSlot]: pinned landing areas of submit()
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '
