@@ -98,9 +98,14 @@ def test_ddp_step_keeps_replicas_in_sync_gloo():
 
 
 @pytest.mark.gpu
-def test_gpu_train_steps_with_device_encoder(tmp_path):
-    """train_dist.main on the GPU: annotations -> HIP encoder -> fused HIP losses -> optimizer, a few steps."""
+def test_gpu_train_steps_with_device_encoder(tmp_path, monkeypatch):
+    """train_dist.main on the GPU: annotations -> HIP encoder -> fused HIP losses -> optimizer, a few steps.  The epoch's
+    checkpoint is handed to the test instead of the disk (2.2 GB of Hourglass-104 weights + Adam moments took half of this
+    test's time; the file round trip is test_resume_restores_epoch_weights_and_optimizer's)."""
     import torch
+    from offsetguided_amd.models import networks
+    saved = []
+    monkeypatch.setattr(networks.torch, 'save', lambda data, path: saved.append((data, str(path))))
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected but no HIP device is visible")
     from offsetguided_amd import encoder, train_dist
@@ -115,6 +120,11 @@ def test_gpu_train_steps_with_device_encoder(tmp_path):
     assert bool(torch.isfinite(off).any()) and bool(torch.isinf(off).any()) and float(ps.min()) >= 1.0
     train_dist.main(['--no-pretrain', '--square-length', '256', '--batch-size', '2', '--epochs', '1', '--steps-per-epoch', '3',
                      '--print-freq', '1', '--checkpoint-path', str(tmp_path)])
+    (data, path), = saved
+    assert path.startswith(str(tmp_path)) and data['epoch'] == 0 and np.isfinite(data['train_loss'])
+    assert all(bool(torch.isfinite(v).all()) for v in data['model_state_dict'].values() if v.is_floating_point())
+    steps = [int(st['step']) for st in data['optimizer_state_dict']['state'].values()]
+    assert steps and all(n == 3 for n in steps)
 
 
 def test_resume_restores_epoch_weights_and_optimizer(tmp_path, monkeypatch, capsys):
