@@ -733,7 +733,7 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
 #define TILED_LAUNCH(TW_, TH_, WM_, VAR_)                                                                             \
     do {                                                                                                              \
         constexpr int halo_ = ((TW_ + 2) * (TH_ + 2) * 5 * 16 + 1023) / 1024 * 1024;                                  \
-        const int lds_ = 2 * halo_ + 3 * 128 * 64 + 1024;                                                             \
+        const int lds_ = 2 * halo_ + (TW_ == 20 ? OG_TILED_RING20 : TW_ == 40 ? OG_TILED_RING40 : 3) * 128 * 64 + 1024; \
         static OgAttrOnce attr_;                                                                                      \
         if (attr_.need())                                                                                             \
             (void)hipFuncSetAttribute((const void *)conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, 4>,                     \
@@ -741,10 +741,12 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles * h.ksplit;                                  \
         hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, 4>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
     } while (0)
-    // VAR 2 = LDS-DMA issue behind the fragment reads (measured best; the other tuning variants -- weight-fragment prefetch,
-    // 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only ablations -- are described in EXPERIMENTS.md)
+    // VAR 10 = 8 (the step's DMA issue, all but two of its weight-fragment reads and the next step's pixel-fragment reads go BETWEEN its
+    // MFMAs, one item per gap: round 5, -1...-1.5 % of the network step) + 2 (LDS-DMA issue behind the fragment reads: what 8 replaces;
+    // the other tuning variants -- weight-fragment prefetch, 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only
+    // ablations -- are described in EXPERIMENTS.md)
 #ifndef OG_TILED_VAR16
-#define OG_TILED_VAR16 2
+#define OG_TILED_VAR16 10
 #endif
     if (kind == 1) TILED_LAUNCH(16, 16, 4, OG_TILED_VAR16);
     else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
@@ -809,8 +811,11 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
         hipLaunchKernelGGL((conv3x3s2_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_,   \
                            (hipStream_t)stream, h);                                                                   \
     } while (0)
-    if (kind == 2) S2_LAUNCH(40, 2, 1, 2);
-    else S2_LAUNCH(16, 8, 2, 2);       // DMA issue behind the fragment reads: measured 1-4 % faster
+#ifndef OG_S2_VAR
+#define OG_S2_VAR 10
+#endif
+    if (kind == 2) S2_LAUNCH(40, 2, 1, OG_S2_VAR);
+    else S2_LAUNCH(16, 8, 2, OG_S2_VAR);       // 2 = DMA issue behind the fragment reads (1-4 % faster), 8 = issue items between the MFMAs
 #undef S2_LAUNCH
     OG_LAUNCH_CHECK(name);
     return OG_OK;

@@ -25,19 +25,27 @@ def main():
     dt = torch.bfloat16
     cl = torch.channels_last
     fn = _lib.lp(lib, 'og_conv3x3_tiled', dt)
-    wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(dt).contiguous(memory_format=cl)
-    packed = torch.empty(wt.numel(), dtype=dt, device=dev)
-    _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
-    bias = torch.zeros(256, device=dev)
     for spec in a.shapes.split(','):
-        n, hw = (int(v) for v in spec.split('x'))
-        xs = [torch.randn(n, 256, hw, hw, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
-        wgs = n * (hw // 16) ** 2 * 2
+        shape, _, chans = spec.partition(':')              # NxHW[:CINxCOUT], e.g. 8x160 or 8x40:384x384
+        n, hw = (int(v) for v in shape.split('x'))
+        cin, cout = (int(v) for v in chans.split('x')) if chans else (256, 256)
+        wt = (torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / (9 * cin)) ** 0.5).to(dt).contiguous(memory_format=cl)
+        packed = torch.empty(wt.numel(), dtype=dt, device=dev)
+        _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), cin, cout, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
+        bias = torch.zeros(cout, device=dev)
+        xs = [torch.randn(n, cin, hw, hw, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
+        outs = [torch.empty(n, cout, hw, hw, device=dev, dtype=dt).contiguous(memory_format=cl) for _ in range(3)]
+        tw, th = (16, 16) if hw % 16 == 0 else (hw, 4)
+        items = n * (hw // th) * (hw // tw) * (cout // 128)
+        chunks = cin // 32
+        ksplit = 1 if items >= 200 or tw == 16 else (2 if chunks % 4 == 0 else 1) if tw == 20 else (3 if chunks % 6 == 0 else 1)   # tiled_ksplit
+        wgs = items * ksplit
         stamps = torch.zeros(wgs * 4 * 16, dtype=torch.int64, device=dev)
+        ws = torch.zeros(max(int(lib.og_conv3x3_tiled_workspace_bytes(n, hw, hw, cin, cout)), 256), dtype=torch.uint8, device=dev)
 
         def once(i):
-            _lib.check(fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(xs[(i + 1) % 3]), _lib.ptr(xs[(i + 2) % 3]),
-                          n, hw, hw, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
+            _lib.check(fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(outs[(i + 1) % 3]), _lib.ptr(outs[i % 3]),
+                          n, hw, hw, cin, cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
         lib.og_conv3x3_debug_stamps(None)
         for i in range(a.warm):          # the clock the chip holds under this load
             once(i)
@@ -46,6 +54,7 @@ def main():
         lib.og_conv3x3_debug_stamps(None)
         torch.cuda.synchronize()
         s = stamps.view(wgs, 4, 16).double().cpu()
+        s[..., 8] = torch.where(s[..., 8] == 0, s[..., 6], s[..., 8])      # K slices that are not the last arriver leave behind the loop
         steps = s[..., 3]
         per = lambda k: (s[..., k] / steps)
         loop_us = (s[..., 6] - s[..., 5]) / 100.0
@@ -62,7 +71,7 @@ def main():
         for name, k in (('wait', 0), ('barrier', 1), ('reads+dma+mfma', 2)):
             v = per(k)
             print(f'   {name:16s} {v.mean():7.1f} cycles per step  (p10 {v.flatten().quantile(0.1):7.1f}, p90 {v.flatten().quantile(0.9):7.1f})')
-        print(f'   {"step":16s} {tot.mean():7.1f} cycles  (512 = the 32 MFMAs alone)')
+        print(f'   {"step":16s} {tot.mean():7.1f} cycles  (MFMAs alone: 512 at 16 x 16, 320 at 40 x 4, 160 at 20 x 4)')
         # slot occupancy per CU: workgroups grouped by (XCC, SE, CU) from HW_ID; the time a CU holds fewer than two workgroups
         hw = s[:, 0, 10].long()
         xcc = s[:, 0, 11].long() & 15

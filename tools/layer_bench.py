@@ -23,12 +23,16 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--dtype', choices=['bf16', 'f16'], default='f16')
+    ap.add_argument('--only', default='', help="comma list of kind:Hin to run, e.g. s1:20,s1:40 (default: every layer)")
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     cl = torch.channels_last
+    only = set(filter(None, a.only.split(',')))
     for kind, n, hin, cin, cout, count in LAYERS:
+        if only and f'{kind}:{hin}' not in only:
+            continue
         taps = 1 if kind in ('pw', 'hd') else 9
         hout = hin // 2 if kind == 's2' else hin
         xs = [torch.randn(n, cin, hin, hin, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
