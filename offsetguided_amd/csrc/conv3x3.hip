@@ -811,11 +811,8 @@ OG_API int OG_LP_NAME(og_conv3x3s2_tiled)(const void *x, const void *w_packed, c
         hipLaunchKernelGGL((conv3x3s2_tiled_kernel<TW_, TH_, WM_, VAR_>), dim3((unsigned)blocks_), dim3(256), lds_,   \
                            (hipStream_t)stream, h);                                                                   \
     } while (0)
-#ifndef OG_S2_VAR
-#define OG_S2_VAR 10
-#endif
-    if (kind == 2) S2_LAUNCH(40, 2, 1, OG_S2_VAR);
-    else S2_LAUNCH(16, 8, 2, OG_S2_VAR);       // 2 = DMA issue behind the fragment reads (1-4 % faster), 8 = issue items between the MFMAs
+    if (kind == 2) S2_LAUNCH(40, 2, 1, 2);
+    else S2_LAUNCH(16, 8, 2, 2);       // DMA issue behind the fragment reads: measured 1-4 % faster
 #undef S2_LAUNCH
     OG_LAUNCH_CHECK(name);
     return OG_OK;
