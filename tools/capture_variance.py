@@ -26,7 +26,7 @@ def main():
     attr, vals = None, [None]
     if len(sys.argv) > 2:
         attr, vs = sys.argv[2].split('=')
-        vals = [int(v) for v in vs.split(',')]
+        vals = [int(v) for v in vs.split(',')]          # (negative values allowed: stream priorities)
     engines = []
     for i in range(r):
         if attr:
