@@ -741,12 +741,12 @@ int conv3x3_tiled_impl(const char *name, const void *x, const void *w_packed, co
         const long blocks_ = (long)N * (H / TH_) * (W / TW_) * h.n_tiles * h.ksplit;                                  \
         hipLaunchKernelGGL((conv3x3_tiled_kernel<TW_, TH_, WM_, VAR_, 4>), dim3((unsigned)blocks_), dim3(256), lds_, st, h); \
     } while (0)
-    // VAR 10 = 8 (the step's DMA issue, all but two of its weight-fragment reads and the next step's pixel-fragment reads go BETWEEN its
-    // MFMAs, one item per gap: round 5, -1...-1.5 % of the network step) + 2 (LDS-DMA issue behind the fragment reads: what 8 replaces;
-    // the other tuning variants -- weight-fragment prefetch, 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only
-    // ablations -- are described in EXPERIMENTS.md)
+    // VAR 26 = 16 (next step's weight fragments in rotating register sets; the step's DMA issue and every fragment read BETWEEN its MFMAs,
+    // one item per gap: round 5, -2 % of the network step) + 8 + 2 (what 16 replaces: LDS-DMA issue behind the fragment reads; the other
+    // tuning variants -- weight-fragment prefetch, 2 x 2 waves, 8 waves, 20 x 4 tiles at 40x40, no XCD remap, the timing-only ablations --
+    // are described in EXPERIMENTS.md)
 #ifndef OG_TILED_VAR16
-#define OG_TILED_VAR16 10
+#define OG_TILED_VAR16 26
 #endif
     if (kind == 1) TILED_LAUNCH(16, 16, 4, OG_TILED_VAR16);
     else if (kind == 3) TILED_LAUNCH(20, 4, 1, 2);
