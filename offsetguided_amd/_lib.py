@@ -160,6 +160,63 @@ def workspace(device, nbytes, tag="ws"):
     return buf
 
 
+_own_streams = {}
+
+
+def dedicated_stream(device, key):
+    """A HIP stream of this process's own for (device, key) -- hipStreamCreateWithFlags(non-blocking), wrapped as
+    torch.cuda.ExternalStream, created on first request and kept.  torch.cuda.Stream() hands out a POOL of 32 streams in turn: after
+    enough engines (seven side streams each), copy streams and capture streams have been made, a "new" torch.cuda.Stream() IS one of
+    those, and a graph launch on a lane that also sits in that graph's capture history crashed the runtime (segfault in
+    hipGraphLaunch, round 5: run_images with two lanes after a few engine builds).  The lanes, the decoder's grouping streams and the
+    input-chain streams come from here.  (The engines' capture-time side streams stay torch pool streams: which of them end up on
+    which hardware queue decides 3 % of the step, and the pool's order is the measured one -- profiles/r05_inflight_streams.log.)"""
+    k = (device.index, key)
+    st = _own_streams.get(k)
+    if st is None:
+        hip = _hip_runtime()
+        with torch.cuda.device(device):
+            h = C.c_void_p()
+            rc = hip.hipStreamCreateWithFlags(C.byref(h), C.c_uint(1))      # hipStreamNonBlocking
+            if rc != 0:
+                raise OgError(f'hipStreamCreateWithFlags failed ({rc})')
+            st = _own_streams[k] = torch.cuda.ExternalStream(h.value, device=device)
+    return st
+
+
+_free_streams = {}
+
+
+def new_stream(device):
+    """A HIP stream of this process's own for ONE owner at a time (an engine's side branch during its capture): like dedicated_stream,
+    but handed out per call; release_stream() puts its handle on a free list that serves the next caller first -- torch.cuda.Stream()'s
+    pool of 32 repeats whoever still uses what.  Streams are created in the order they are asked for, as the pool's were: which
+    capture-time stream sits on which hardware queue is worth 3 % of the step (profiles/r05_inflight_streams.log).  (No finalizer on
+    the wrapper objects: weakref.finalize on them crashed the interpreter at exit.)"""
+    free = _free_streams.setdefault(device.index, set())
+    if free:
+        handle = free.pop()
+    else:
+        hip = _hip_runtime()
+        with torch.cuda.device(device):
+            h = C.c_void_p()
+            rc = hip.hipStreamCreateWithFlags(C.byref(h), C.c_uint(1))      # hipStreamNonBlocking
+            if rc != 0:
+                raise OgError(f'hipStreamCreateWithFlags failed ({rc})')
+            handle = h.value
+    return torch.cuda.ExternalStream(handle, device=device)
+
+
+def release_stream(stream):
+    """The owner is done with a new_stream() stream (work already queued on it stays ordered: the next owner queues behind it)."""
+    _free_streams.setdefault(stream.device.index, set()).add(stream.cuda_stream)
+
+
+def lane_streams(device, n):
+    """The n streams batches in flight run on (evaluate.run_images, bench.py): dedicated_stream(device, ('lane', i))."""
+    return [dedicated_stream(device, ('lane', i)) for i in range(n)]
+
+
 _const_cache = {}
 
 

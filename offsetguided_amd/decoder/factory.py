@@ -108,6 +108,8 @@ class PendingPoses:
 
 
 class PostProcess(torch.nn.Module):
+    _made = 0          # instances that took a side stream (which of the process's K3 streams the next one gets)
+
     def __init__(self, batch_size, hmp_stride, off_stride, inter_mode, keypoints, skeleton,
                  limb_collector, limb_grouper, include_scale=False, include_jitter_offset=False,
                  hmp_index=0, omp_index=1, feat_stage=-1):
@@ -163,7 +165,8 @@ class PostProcess(torch.nn.Module):
         if self.group_on_side_stream:
             stream = self._side.get(dev.index)
             if stream is None:
-                stream = self._side[dev.index] = torch.cuda.Stream(dev)
+                PostProcess._made += 1       # (a stream of the process's own: torch's pool of 32 repeats, _lib.dedicated_stream)
+                stream = self._side[dev.index] = _lib.dedicated_stream(dev, ('k3', PostProcess._made % 8))
             stream.wait_stream(cur)
             limbs.record_stream(stream)
         with torch.cuda.stream(stream):

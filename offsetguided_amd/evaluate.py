@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import decoder, models
+from . import _lib, decoder, models
 from .utils import AverageMeter
 
 LOG = logging.getLogger(__name__)
@@ -109,7 +109,12 @@ def synthetic_loader(n_batches, batch_size, size, device, seed=0):
         yield images, [None] * batch_size, metas
 
 
-ENGINE_CACHE = 4     # engines (input shapes) run_images keeps alive
+ENGINE_CACHE = 4     # input shapes run_images keeps engines for
+# Batches in flight: batch i runs whole (backbone graph + decoder) on HIP stream i % IN_FLIGHT with that lane's PostProcess; the head
+# and tail of one forward (stem, final layers, heads, decoder: few workgroups) then run beside the bulk of the next.  A shape whose
+# batches follow each other gets a second engine (captured graph + activations; the weights are shared, models/engine.py:_shared_layers)
+# so that two of them can run at once.  Measured on bench.py's loop: 2 = +1.6...2.1 %, 3 = nothing more.
+IN_FLIGHT = 2
 
 
 def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
@@ -123,16 +128,18 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
         if args.resume:
             model, *_ = models.load_model(model, args.checkpoint_whole, optimizer=None, resume_optimizer=False,
                                           drop_layers=False, load_amp=False)
-    processor = decoder.decoder_factory(args)
+    processors = [decoder.decoder_factory(args) for _ in range(IN_FLIGHT)]
+    lanes = _lib.lane_streams(dev, IN_FLIGHT) if IN_FLIGHT > 1 else [torch.cuda.current_stream(dev)]
     if data_loader is None:
         data_loader = synthetic_loader(n_synthetic_batches, args.batch_size, args.long_edge, dev)
     feeder = DeviceFeeder(dev)
-    # one engine (scratch + captured graph) per input shape, the ENGINE_CACHE most recently used ones kept (--fixed-height: one
-    # shape per width); the folded / tiled weights are shared between them (models/engine.py:_shared_layers); a ragged last batch
-    # is padded instead of getting an engine of its own
+    # engines (scratch + captured graph) per input shape, those of the ENGINE_CACHE most recently used shapes kept (--fixed-height:
+    # one shape per width); the folded / tiled weights are shared between them (models/engine.py:_shared_layers); a ragged last
+    # batch is padded instead of getting an engine of its own.  A shape has one engine until two batches of it follow each other
+    # closer than IN_FLIGHT apart: then the one still busy is left alone and another is built (at most IN_FLIGHT per shape)
     import collections
-    engines = collections.OrderedDict()
-    batch_time, end, last_print, pending = AverageMeter(), time.time(), -1, None
+    engines = collections.OrderedDict()                      # shape -> [[engine, index of the last batch it ran, event behind that batch], ...]
+    batch_time, end, last_print, pending = AverageMeter(), time.time(), -1, collections.deque()
     full_batch = None
 
     def collect(handle):
@@ -184,21 +191,34 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                 images = torch.cat((images, images[-1:].expand(full_batch - images.shape[0], -1, -1, -1)))
             if args.flip_test:
                 images = torch.cat((images, torch.flip(images, [-1])))
-            engine = engines.pop(tuple(images.shape), None)
-            if engine is None:
+            lane = batch_idx % len(lanes)
+            of_shape = engines.pop(tuple(images.shape), None)
+            if of_shape is None:
                 if len(engines) >= ENGINE_CACHE:
-                    if pending is not None:      # the batch in flight still reads the outputs of the engine that goes
-                        collect(pending)
-                        pending = None
+                    while pending:               # the batches in flight still read the outputs of the engines that go
+                        collect(pending.popleft())
                     engines.popitem(last=False)
-                engine = models.InferenceEngine(model, images.shape[0], images.shape[2], images.shape[3], device=dev,
-                                                feat_stage=args.feat_stage)
-            engines[tuple(images.shape)] = engine            # most recently used last
-            outputs = engine(images)
-            handle = (processor.submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
-            if pending is not None:
-                collect(pending)
-            pending = handle
+                of_shape = []
+            engines[tuple(images.shape)] = of_shape          # most recently used last
+            slot = min(of_shape, key=lambda e: e[1], default=None)           # the engine of this shape that has rested longest
+            if slot is None or (batch_idx - slot[1] < len(lanes) and len(of_shape) < len(lanes)):
+                slot = [models.InferenceEngine(model, images.shape[0], images.shape[2], images.shape[3], device=dev,
+                                               feat_stage=args.feat_stage), -len(lanes), None]
+                of_shape.append(slot)
+            cur = torch.cuda.current_stream(dev)
+            if lanes[lane] is not cur:
+                lanes[lane].wait_stream(cur)                 # the input chain (H2D copy, rescale / pad / normalize, flip) ran on `cur`
+                images.record_stream(lanes[lane])
+            if slot[2] is not None:
+                lanes[lane].wait_event(slot[2])              # the engine's last batch (maybe on another lane): its decoder has read the outputs
+            with torch.cuda.stream(lanes[lane]):
+                outputs = slot[0](images)
+                handle = (processors[lane].submit(outputs, flip_test=args.flip_test, cat_flip_offs=args.cat_flip_offset), metas)
+                slot[1], slot[2] = batch_idx, torch.cuda.Event()
+                slot[2].record(lanes[lane])
+            pending.append(handle)
+            while len(pending) > len(lanes):                 # the oldest batch: its poses are on the host by now (or soon)
+                collect(pending.popleft())
             if batch_idx % args.print_freq == 0:
                 torch.cuda.synchronize()
                 now = time.time()
@@ -209,8 +229,8 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                 print('==================> [{0}]\tTime {1:.3f} ({2:.3f})\tSpeed {3:.3f} ({4:.3f})'.format(
                     batch_idx, per_batch, batch_time.avg or per_batch, args.batch_size / per_batch,
                     args.batch_size / (batch_time.avg or per_batch)))
-        if pending is not None:
-            collect(pending)
+        while pending:
+            collect(pending.popleft())
     finally:
         # also on an exception (engine build failure, OgError, the --fixed-height assertion): the worker must not outlive the
         # call holding pinned staging buffers, and a pack still queued must not write one while the caller handles the error
@@ -226,7 +246,7 @@ class DeviceFeeder:
 
     def __init__(self, device):
         self.device = device
-        self.stream = torch.cuda.Stream(device)
+        self.stream = _lib.dedicated_stream(device, ('feeder',))
         self.slots, self.turn = [None, None], 0
 
     def __call__(self, images):

@@ -121,6 +121,7 @@ class _Issuer(threading.local):
 
 
 _issuer = _Issuer()
+_warm_streams = {}
 _n_engines = 0
 
 
@@ -490,6 +491,7 @@ class _Level:
     def __call__(self, x):
         if BRANCHES and x.is_cuda and self.depth <= BRANCH_MAX_DEPTH:
             cur = torch.cuda.current_stream(x.device)
+            # (streams of the process's own, one owner each: _lib.new_stream)
             # side streams belong to the ENGINE that issues the work (the levels themselves are shared by the engines of one model,
             # _shared_layers): two engines in flight must not serialise their branches on one stream
             key = (x.device.index, _issuer.engine)
@@ -497,12 +499,12 @@ class _Level:
             if side is None:
                 if DEEP_SHARED and self.depth >= DEEP_SHARED:
                     if getattr(_issuer, 'deep_side', None) is None or _issuer.deep_side[0] != key:
-                        _issuer.deep_side = (key, torch.cuda.Stream(x.device))
+                        _issuer.deep_side = (key, _lib.new_stream(x.device))
                     side = _issuer.deep_side[1]
                 else:
-                    side = torch.cuda.Stream(x.device)
-                if len(self._side) >= 8:        # engines come and go (evaluate.run_images keeps four per model): forget the oldest
-                    self._side.pop(next(iter(self._side)))
+                    side = _lib.new_stream(x.device)
+                if len(self._side) >= 8:        # engines come and go (evaluate.run_images keeps four shapes per model): forget the oldest
+                    _lib.release_stream(self._side.pop(next(iter(self._side))))     # (its graph was captured long ago)
                 self._side[key] = side
             box = {}
             trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST
@@ -742,13 +744,18 @@ class InferenceEngine:
         return (hm, off) + extra
 
     def _capture(self):
-        side = torch.cuda.Stream(self.device)
+        side = _lib.new_stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):                      # warm-up: weight tiling / packing, workspaces, allocator
                 self._forward(self._static_in)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        # the warm-up stream goes back with the side streams of the eighth engine before this one (every engine MAKES eight streams: that
+        # keeps each engine's branches on the hardware queues the first engine's sit on -- _lib.new_stream)
+        _warm_streams[(self.device.index, self._id)] = side
+        if len(_warm_streams) > 8:
+            _lib.release_stream(_warm_streams.pop(next(iter(_warm_streams))))
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             self._out = self._forward(self._static_in)

@@ -80,7 +80,7 @@ class EvalPreprocess:
         self._mean, self._std, self._fill = f3(mean), f3(std), f3(fill)
         self._stage, self._turn = [None, None, None], 0
         self._pack_lock = __import__('threading').Lock()   # ONE pack at a time (see pack)
-        self.copy_stream = torch.cuda.Stream(self.device)
+        self.copy_stream = _lib.dedicated_stream(self.device, ('input-chain',))    # (not torch's repeating pool of 32)
 
     def _staging(self, nbytes):
         buf = self._stage[self._turn]

@@ -174,7 +174,8 @@ def test_two_rank_bench_on_the_gpu():
     two = torch.cuda.device_count() >= 2
     env = _clean_env() if two else _clean_env(OG_BENCH_SHARE_DEVICE='1')
     r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
-                        '--no-extras'], capture_output=True, text=True, timeout=1500, env=env)
+                        '--no-extras', '--inflight', '1'],      # (one batch in flight: two ranks on one device build four engines otherwise)
+                       capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
