@@ -209,10 +209,13 @@ def test_run_images_values(dev, stage, monkeypatch):
     assert n_real > 0, 'the default-init model should yield pseudo-poses above the thresholds'
 
 
-def test_run_images_from_raw_uint8_images(dev, monkeypatch):
+@pytest.mark.parametrize("in_flight", [2, 1, 3])
+def test_run_images_from_raw_uint8_images(dev, monkeypatch, in_flight):
     """The harness fed with raw uint8 images of mixed sizes: the device input chain (EvalPreprocess) supplies the network
-    input and the metas; results map back to ORIGINAL image coordinates through annotations_inverse."""
+    input and the metas; results map back to ORIGINAL image coordinates through annotations_inverse.  With two batches in flight
+    (evaluate.IN_FLIGHT, the default: the second batch of the same shape gets a second engine on the other lane), one, and three."""
     from offsetguided_amd import evaluate, transforms
+    monkeypatch.setattr(evaluate, 'IN_FLIGHT', in_flight)
     torch.manual_seed(0)
     a = evaluate.evaluate_cli(['--no-pretrain', '--initialize-whole', 'False', '--topk', '32', '--thre-hmp', '0.04',
                                '--person-thre', '0.04', '--dist-max', '40', '--long-edge', '256', '--batch-size', '2',
