@@ -99,7 +99,9 @@ BRANCH_MAX_DEPTH = int(os.environ.get('OG_ENGINE_BRANCH_MAX_DEPTH', '4'))   # fo
 # "fork point -> up1 -> merge" stays on one hardware queue and the latency-critical trunk is moved to a new one -- every merge
 # then waits across queues for the trunk (11 us in the forward timeline).  Trunk first: the trunk keeps its queue through forks
 # and merges, a fork costs it ~6 us instead (the release behind the fork point).
-TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '1'))
+# Default 2 since round 5 (two batches in flight, faster small levels): 5.859 vs 5.894 ms per step for 1, seven of seven repeats
+# (profiles/r05_capture_order_ab.log); 3: 5.91.
+TRUNK_FIRST = int(os.environ.get('OG_ENGINE_TRUNK_FIRST', '2'))
 # OG_ENGINE_DEEP_SHARED = D (default 3; 0 = off): the up1 branches of the levels of depth >= D share ONE side stream, in the order
 # the trunk forks them (depth 3, then depth 4): the graph executor otherwise puts the inner branches on one hardware queue DEEPEST
 # first, so the 20x20 branch of depth 3 -- ready when the trunk enters depth 3 -- only starts behind the 10x10 branch of depth 4

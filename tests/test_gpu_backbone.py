@@ -709,12 +709,12 @@ def test_engine_f16_matches_reference_golden(dev):
 
 
 @pytest.mark.parametrize("knobs", [{"OG_CONV_UP2": "0", "OG_ENGINE_TRUNK_FIRST": "0"},
-                                   {"OG_ENGINE_TRUNK_FIRST": "2", "OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"},
+                                   {"OG_ENGINE_TRUNK_FIRST": "1", "OG_CONV_BAND_MAX_PIXELS": "0", "OG_ENGINE_DEEP_SHARED": "0"},
                                    {"OG_ENGINE_DEEP_SHARED": "2"}])
 def test_engine_schedule_knobs(dev, knobs):
     """The engine's kept A/B switches (read at import), every non-default value in one of three child processes: merges as their own
     launches instead of on the producing convolution's epilogue + the up1 branch captured before the trunk below the fork; trunk-first
-    from depth 2 + the small levels back on the split-K kernel with every up1 branch on its own stream; the inner branches sharing a
+    from depth 1 + the small levels back on the split-K kernel with every up1 branch on its own stream; the inner branches sharing a
     stream from depth 2 -- the bench-shape engine test (graph replay against the eager model) again in each."""
     import os
     import subprocess
