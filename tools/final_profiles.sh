@@ -16,7 +16,7 @@ kt=$(ls "$out"/stats/*/*_kernel_trace.csv | head -1)
 ks=$(ls "$out"/stats/*/*_kernel_stats.csv | head -1)
 cp "$ks" "$out/bench_kernel_stats_raw.csv"
 python3 "$root/tools/postfind_stats.py" "$kt" "$out/bench_kernel_stats_postfind.csv"
-python3 "$root/tools/forward_timeline.py" "$kt" "$out/forward_timeline.csv" > "$out/forward_timeline_summary.txt" 2>&1
+# (one forward's timeline: tools/timeline_env.sh, with ONE batch in flight -- two interleave their kernels; below)
 rm -rf "$out/stats"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python3 "$root/tools/k1_bench.py" --iters 10 --rotate 3 --forms two > "$out/k1_$c.log" 2>&1
@@ -24,6 +24,8 @@ done
 python3 "$root/tools/pmc_traffic.py" "$out"/pmc_FETCH_SIZE/*/*_counter_collection.csv "$out"/pmc_WRITE_SIZE/*/*_counter_collection.csv "$out/k1_traffic.json" > "$out/k1_traffic.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do cp "$out"/pmc_$c/*/*_counter_collection.csv "$out/k1_pmc_$c.csv"; rm -rf "$out/pmc_$c"; done
 cd "$root"
+bash tools/timeline_env.sh $tag > /dev/null 2>&1
+cp "$root/gpurun_out/${tag}_timeline.csv" "$out/forward_timeline.csv"; cp "$root/gpurun_out/${tag}_timeline_summary.txt" "$out/forward_timeline_summary.txt"
 bash tools/prof_c1.sh "gpurun_out/$tag/c1" > "$out/c1_pmc.log" 2>&1
 cp "$out/c1/c1_pmc_summary.csv" "$out/c1_pmc_summary.csv" 2>/dev/null
 rm -rf "$out/c1"
