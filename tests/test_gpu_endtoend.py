@@ -392,3 +392,29 @@ def test_engine_precision_at_the_pose_level(dev, dtype, min_common):
     assert strong > 20 and strong_common >= 0.95 * strong
     assert common >= min_common * tot
     assert dscore <= {torch.bfloat16: 2e-3, torch.float16: 3e-4, torch.float32: 1e-5}[dtype]
+
+
+def test_own_streams_are_distinct_and_reused_only_after_release(dev):
+    """_lib.dedicated_stream / new_stream / release_stream: the process's own HIP streams (torch.cuda.Stream() repeats a pool of 32).
+    A key always gets the same stream; new_stream() never hands out a live stream twice -- 40 of them are 40 different handles, none of
+    them a lane -- and a released handle is what the next caller gets."""
+    from offsetguided_amd import _lib
+    lanes = _lib.lane_streams(dev, 2)
+    assert [s.cuda_stream for s in lanes] == [s.cuda_stream for s in _lib.lane_streams(dev, 2)] and lanes[0].cuda_stream != lanes[1].cuda_stream
+    assert _lib.dedicated_stream(dev, ('k3', 1)).cuda_stream == _lib.dedicated_stream(dev, ('k3', 1)).cuda_stream
+    mine = [_lib.new_stream(dev) for _ in range(40)]
+    handles = {s.cuda_stream for s in mine}
+    assert len(handles) == 40 and not handles & {s.cuda_stream for s in lanes}
+    x = torch.ones(1 << 16, device=dev)
+    with torch.cuda.stream(mine[7]):
+        y = x * 3
+    mine[7].synchronize()
+    assert float(y.sum()) == 3 * (1 << 16)
+    for s in mine[:5]:
+        _lib.release_stream(s)
+    again = {_lib.new_stream(dev).cuda_stream for _ in range(5)}
+    assert again == {s.cuda_stream for s in mine[:5]}
+    for s in mine[5:]:
+        _lib.release_stream(s)
+    for h in again:
+        _lib._free_streams[dev.index].add(h)
