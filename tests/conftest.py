@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# torch's eager convolutions (the fp32 references of the GPU tests, the DDP step) go through MIOpen: its default find mode benchmarks every
+# new problem for seconds; FAST takes the heuristic's pick (the product path has no MIOpen call)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
