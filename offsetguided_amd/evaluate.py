@@ -109,7 +109,8 @@ def synthetic_loader(n_batches, batch_size, size, device, seed=0):
         yield images, [None] * batch_size, metas
 
 
-ENGINE_CACHE = 4     # input shapes run_images keeps engines for
+ENGINE_CACHE = 8     # input shapes run_images keeps engines for (--fixed-height: one per padded width, a handful on COCO; an engine
+                     # holds its activations + graph, ~0.1 GB per image of 640x640, the weights are shared)
 # Batches in flight: batch i runs whole (backbone graph + decoder) on HIP stream i % IN_FLIGHT with that lane's PostProcess; the head
 # and tail of one forward (stem, final layers, heads, decoder: few workgroups) then run beside the bulk of the next.  A shape whose
 # batches follow each other gets a second engine (captured graph + activations; the weights are shared, models/engine.py:_shared_layers)

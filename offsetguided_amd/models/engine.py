@@ -120,6 +120,7 @@ class _Issuer(threading.local):
     engine = 0
     branch = 0
     build_device = None   # device the folded weights of the engine under construction go to
+    ws = None             # the issuing engine's scratch buffers (None: a bare _Conv call outside an engine -> the module's _conv_ws)
 
 
 _issuer = _Issuer()
@@ -128,13 +129,16 @@ _n_engines = 0
 
 
 def _conv3x3_workspace(device, nbytes):
-    """One zero-initialised scratch per (device, concurrent branch) for og_conv3x3_bf16 (zero page + split-K slabs).
-    Layers of one branch run back to back on one stream, so they share it; it only ever grows outside graph capture."""
-    key = (device.index, _issuer.engine, _issuer.branch)
-    buf = _conv_ws.get(key)
+    """One zero-initialised scratch per (engine, device, concurrent branch) for og_conv3x3_bf16 (zero page + split-K slabs).
+    Layers of one branch run back to back on one stream, so they share it; it only ever grows outside graph capture.  The
+    buffers belong to the ENGINE that issues the work (_issuer.ws = InferenceEngine._ws) and go with it: a process-wide cache keyed
+    by engine id kept ~17 MB per engine ever built (run_images --fixed-height builds one per new width)."""
+    ws = _issuer.ws if _issuer.ws is not None else _conv_ws
+    key = (device.index, _issuer.branch)
+    buf = ws.get(key)
     if buf is None or buf.numel() < nbytes:
         assert not torch.cuda.is_current_stream_capturing(), 'conv3x3 workspace must be sized before graph capture'
-        buf = _conv_ws[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        buf = ws[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
     return buf
 
 
@@ -505,7 +509,7 @@ class _Level:
                     side = _issuer.deep_side[1]
                 else:
                     side = _lib.new_stream(x.device)
-                if len(self._side) >= 8:        # engines come and go (evaluate.run_images keeps four shapes per model): forget the oldest
+                if len(self._side) >= 32:       # engines come and go (evaluate.run_images keeps 8 shapes x 2 lanes per model): forget the oldest
                     _lib.release_stream(self._side.pop(next(iter(self._side))))     # (its graph was captured long ago)
                 self._side[key] = side
             box = {}
@@ -670,6 +674,7 @@ class InferenceEngine:
         self._layers = _shared_layers(model, dtype, self.device, self.stage, self.fused)
         for name in _Layers.FIELDS:
             setattr(self, name, getattr(self._layers, name))
+        self._ws = {}                    # this engine's convolution scratch (_conv3x3_workspace)
         self._static_in = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         self._graph = None
         self._out = None
@@ -677,7 +682,7 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
-        _issuer.engine = self._id
+        _issuer.engine, _issuer.ws = self._id, self._ws
         if self.stem_w is not None:   # fused stem: fp32 NCHW images -> conv 7x7 s2 + BN + ReLU -> bf16 NHWC
             lib = _lib.load()
             images = images.float().contiguous()
@@ -753,10 +758,10 @@ class InferenceEngine:
                 self._forward(self._static_in)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        # the warm-up stream goes back with the side streams of the eighth engine before this one (every engine MAKES eight streams: that
+        # the warm-up stream goes back with the side streams of the 32nd engine before this one (every engine MAKES eight streams: that
         # keeps each engine's branches on the hardware queues the first engine's sit on -- _lib.new_stream)
         _warm_streams[(self.device.index, self._id)] = side
-        if len(_warm_streams) > 8:
+        if len(_warm_streams) > 32:
             _lib.release_stream(_warm_streams.pop(next(iter(_warm_streams))))
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
