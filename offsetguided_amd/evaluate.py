@@ -142,6 +142,7 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
     engines = collections.OrderedDict()                      # shape -> [[engine, index of the last batch it ran, event behind that batch], ...]
     batch_time, end, last_print, pending = AverageMeter(), time.time(), -1, collections.deque()
     full_batch = None
+    first_engine = [None]
 
     def collect(handle):
         poses, metas = handle
@@ -204,7 +205,8 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
             slot = min(of_shape, key=lambda e: e[1], default=None)           # the engine of this shape that has rested longest
             if slot is None or (batch_idx - slot[1] < len(lanes) and len(of_shape) < len(lanes)):
                 slot = [models.InferenceEngine(model, images.shape[0], images.shape[2], images.shape[3], device=dev,
-                                               feat_stage=args.feat_stage), -len(lanes), None]
+                                               feat_stage=args.feat_stage, like=first_engine[0]), -len(lanes), None]
+                first_engine[0] = first_engine[0] or slot[0]      # the module's weights do not change inside one call
                 of_shape.append(slot)
             cur = torch.cuda.current_stream(dev)
             if lanes[lane] is not cur:

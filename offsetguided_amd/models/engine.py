@@ -625,7 +625,8 @@ _LAYER_CACHE_MAX = 2
 def _model_signature(model):
     """Identity of a module's CURRENT weights: storage address, version counter, shape and sum of every parameter and buffer --
     an optimizer step, load_state_dict, .to() or a write through .data changes it, so a cached bundle never serves stale weights
-    (0.2 s for Hourglass-104 on the host, a few ms on the device; an engine build takes seconds)."""
+    (0.15-0.2 s for Hourglass-104 on the host, a few ms on the device: callers that build several engines for one unchanged
+    module pass the first one's bundle on, InferenceEngine(like=...))."""
     sig = 0
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
@@ -656,7 +657,7 @@ class InferenceEngine:
     rounding error) or torch.float32 (plain torch ops: the checking path)."""
 
     def __init__(self, model, batch, height, width, dtype=torch.float16, device='cuda:0', feat_stage=-1,
-                 use_graph=True):
+                 use_graph=True, like=None):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
         global _n_engines
         self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
@@ -671,7 +672,15 @@ class InferenceEngine:
         self.fused = (self.device.type == 'cuda' and dtype in (torch.bfloat16, torch.float16))
         # folded / tiled / packed weights do not depend on the input shape: engines of one (model state, dtype, device, stage)
         # share them (evaluate.run_images builds one engine per input shape, --fixed-height: one per width)
-        self._layers = _shared_layers(model, dtype, self.device, self.stage, self.fused)
+        # like = an engine the caller built for this very module a moment ago (evaluate.run_images: one per shape and lane): its
+        # bundle is taken as it is, without the 0.2 s look at every weight that decides whether a cached bundle is still current
+        if (like is not None and like._model() is model and like.dtype == dtype and like.device == self.device
+                and like.stage == self.stage):
+            self._layers = like._layers
+        else:
+            self._layers = _shared_layers(model, dtype, self.device, self.stage, self.fused)
+        import weakref
+        self._model = weakref.ref(model)
         for name in _Layers.FIELDS:
             setattr(self, name, getattr(self._layers, name))
         self._ws = {}                    # this engine's convolution scratch (_conv3x3_workspace)
