@@ -451,7 +451,10 @@ def main():
             lib = _lib.load()
             cl = torch.channels_last
             lp_t = torch.float16 if a.dtype == 'f16' else torch.bfloat16
-            xs = [torch.randn(nb, 256, 160, 160, device=dev).to(lp_t).contiguous(memory_format=cl) for _ in range(3)]
+            # inputs, residual operands and outputs are SEPARATE buffers: fed back into each other (as this block did until round 5)
+            # the activations grow by ~1.3x per launch, overflow fp16 after ~40 launches and the rest of the measurement runs on
+            # inf / NaN operands -- which the chip multiplies at a higher clock (175 us per launch instead of 217)
+            xs = [torch.randn(nb, 256, 160, 160, device=dev).to(lp_t).contiguous(memory_format=cl) for _ in range(9)]
             wt = (torch.randn(256, 256, 3, 3, device=dev) * (1.0 / 2304) ** 0.5).to(lp_t).contiguous(memory_format=cl)
             cb = torch.zeros(256, device=dev)
             packed = torch.empty(wt.numel(), dtype=lp_t, device=dev)
@@ -459,16 +462,15 @@ def main():
             _lib.check(lib.og_conv3x3_pack_w16(_lib.ptr(wt), 256, 256, 0, _lib.ptr(packed), _lib.stream_ptr(dev)), lib)
 
             def conv_once(i):
-                _lib.check(conv_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[(i + 1) % 3]),
-                                                     _lib.ptr(xs[(i + 2) % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
-            timed(conv_once, 5)
-            # the chip lowers its clock under sustained MFMA load (MI355X_MICROARCH.md "DVFS give-back"): a 3-launch burst from an
-            # idle chip beside the 30 back-to-back launches the figure is quoted on -- both are reported (they agree: the clock settles
-            # inside the first launch; the in-kernel clock itself is measured by tools/c1_stamps.py: 2.0-2.4 GHz, 2.14 on average --
-            # sysfs pp_dpm_sclk reads 95 MHz on these boxes and is not used)
+                _lib.check(conv_fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(xs[3 + i % 3]),
+                                                     _lib.ptr(xs[6 + i % 3]), nb, 160, 160, 256, 256, 1, None, 0, _lib.stream_ptr(dev)), lib)
+            # the figure is the layer's time on a chip that is already working (60 launches before the 30 timed ones): from idle the
+            # first dozen launches run ~15 % slower (the clock ramps UP for ~10 ms: a layer bench that warmed up with five launches
+            # read 226 us where the layer takes 198 -- round 5); the 3-launch burst from an idle chip is reported beside it
+            timed(conv_once, 60)
+            conv_us = timed(conv_once, 30) * 1e3
             time.sleep(0.25)
             burst_us = timed(conv_once, 3) * 1e3
-            conv_us = timed(conv_once, 30) * 1e3
             conv_flop = 2.0 * nb * 160 * 160 * 256 * 2304
             extras['roofline_conv3x3'] = {
                 'kernel': 'C1 = og_conv3x3_tiled_' + a.dtype + ' (conv3x3_tiled_kernel<16,16,4>: two workgroups per CU, pre-tiled weights) on the 160x160 '

@@ -35,6 +35,8 @@ def main():
         bias = torch.zeros(cout, device=dev)
         xs = [torch.randn(n, cin, hw, hw, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]
         outs = [torch.empty(n, cout, hw, hw, device=dev, dtype=dt).contiguous(memory_format=cl) for _ in range(3)]
+        sks = [torch.randn(n, cout, hw, hw, device=dev).to(dt).contiguous(memory_format=cl) for _ in range(3)]      # (fixed residual operands:
+        # fed back from the outputs, the activations overflow after a few dozen launches and the chip runs inf / NaN at a higher clock)
         tw, th = (16, 16) if hw % 16 == 0 else (hw, 4)
         items = n * (hw // th) * (hw // tw) * (cout // 128)
         chunks = cin // 32
@@ -44,7 +46,7 @@ def main():
         ws = torch.zeros(max(int(lib.og_conv3x3_tiled_workspace_bytes(n, hw, hw, cin, cout)), 256), dtype=torch.uint8, device=dev)
 
         def once(i):
-            _lib.check(fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(outs[(i + 1) % 3]), _lib.ptr(outs[i % 3]),
+            _lib.check(fn(_lib.ptr(xs[i % 3]), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(sks[i % 3]), _lib.ptr(outs[i % 3]),
                           n, hw, hw, cin, cout, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), lib)
         lib.og_conv3x3_debug_stamps(None)
         for i in range(a.warm):          # the clock the chip holds under this load
