@@ -406,19 +406,26 @@ conv3x3_kernel(ConvArgs a)
         if (!*flag) return;
         if constexpr (kPrefetchEpi) epilogue_load<BM, BN>(pre, a, m0, n0, wave, lane);   // in flight with the gather
         // all loads of a batch are issued before the first add (one memory round trip per batch, not per slab);
-        // the own slab and slots past ksplit are read out of range, which a buffer load returns as 0
+        // slots past ksplit are read out of range, which a buffer load returns as 0
         // (64-wide tiles: 8 slabs = every plan's K split in ONE round trip; two dependent batches cost 2 us per layer)
 #ifndef OG_GATHER_SLABS
 #define OG_GATHER_SLABS 32
 #endif
         constexpr int kBatch = NT * MT >= 16 ? 1 : OG_GATHER_SLABS / (NT * MT);
+        // the sum runs over ALL slabs in slice order, the own one re-read like the others: the result does not depend on which slice
+        // happened to arrive last (fp32 addition is not associative: adding the others to the own registers made the layer -- and with
+        // it the whole forward -- differ in the last bit from run to run; as in the tiled kernel's K split)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int sp0 = 0; sp0 < a.ksplit; sp0 += kBatch) {
             f32x4 part[kBatch][NT * MT];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 const int sp = sp0 + b;
                 const uint32_t soff = __builtin_amdgcn_readfirstlane(
-                    (sp < a.ksplit && sp != split) ? sp * kSlabBytes : a.ksplit * kSlabBytes);
+                    sp < a.ksplit ? sp * kSlabBytes : a.ksplit * kSlabBytes);
 #pragma unroll
                 for (int i = 0; i < NT * MT; ++i)
                     part[b][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tile_slabs, i * 4096 + tid * 16, soff, 16));

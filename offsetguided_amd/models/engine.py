@@ -74,12 +74,14 @@ def _epilogue(y, bias32, bias_lp, skip, relu, fused):
 
 # Layers with at most this many output pixels (N*H*W) run on the split-K MFMA kernel (og_conv2d_*, epilogue fused): the 10x10 /
 # 5x5 levels at batch 8, and the stride-2 layers whose output is that small.
-CONV3X3_MAX_PIXELS = 4096
-CONV_S2_MAX_PIXELS = 4096
+CONV3X3_MAX_PIXELS = 8192      # (4096 until round 5: with 16 images -- flip-test at batch 8 -- the 40 -> 20 stride-2 layer and the 20x20
+CONV_S2_MAX_PIXELS = 8192      # projections fell through to MIOpen, whose pick was not run-to-run exact, and slower)
+CONV_SPLITK_LAST_RESORT = 1 << 17   # above the preferences: any 3x3 layer up to this size runs on the split-K kernel rather than on MIOpen
 # The large levels' layers run on the tiled kernels (og_conv3x3_tiled_* / og_conv3x3s2_tiled_* / og_conv1x1_tiled_*: two workgroups
 # per CU, pre-tiled weights) where they serve the shape: bit 0 = 3x3 stride 1, bit 1 = 3x3 stride 2, bit 2 = 1x1 / heads.
 CONV_TILED = int(os.environ.get('OG_CONV_TILED', '7'))
-CONV_PW_MIN_PIXELS = 8192        # 1x1 layers below this stay on torch's convolution (the deep projections ride on conv2 instead)
+CONV_PW_MIN_PIXELS = 1024        # 1x1 layers below this stay on torch's convolution (the deep projections ride on conv2 instead;
+                                 # 8192 until round 5: MIOpen's fp16 pick for the first projection of a small input was not run-to-run exact)
 CONV_TILED_MIN_PIXELS = 2048     # 20x20 at batch 8 = 3 200 pixels: 20 x 4 tiles split along K
 # OG_CONV_BAND_MAX_PIXELS = P (default 1024; 0 = off): 3x3 layers (stride 1 | 2, with or without the residual's 1x1 projection) with
 # at most P output pixels run on the band-resident kernel (og_conv_band_*, csrc/conv_band.hip: one 4-wave workgroup per (image,
@@ -204,6 +206,8 @@ class _Conv:
                 if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
                     skip = skip.contiguous(memory_format=torch.channels_last)
                 return self._tiled_s2(x, skip)
+            if pixels <= CONV_SPLITK_LAST_RESORT:      # a shape no tiled kernel serves (e.g. the 20-wide level of 24 images): still ours
+                return self._hip(x, skip)
         return _epilogue(self.raw(x), self.b32, self.b, skip, self.relu, self.fused)
 
     def band_ok(self, x, x2=None, proj=None):
