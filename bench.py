@@ -406,6 +406,9 @@ def main():
     engine, proc, maps, images, nb = pipe.engine, pipe.proc, pipe.maps, pipe.images, pipe.nb
     poses, elapsed_rank, elapsed, stage_us = pipe.timed_region(a.steps, a.warmup)
     pipe_host = list(pipe.host_s)
+    # every convolution of the forward on a hand-written kernel: the engines are strict (a shape none of them serves raises instead of
+    # running on torch / MIOpen); the counter is what a strict=False caller would read
+    engine_info = {'strict': all(e.strict for e in pipe.engines), 'torch_conv_calls': sum(len(e.torch_conv_calls) for e in pipe.engines)}
     per_rank = sharding.gather_to_rank0([round(a.batch * a.steps / elapsed_rank, 2)])   # control plane only
     # The production decoder is K1-fused (PostProcess.fused_upsample): no hi-res tensor, no HBM-streaming K1 in the
     # headline region.  The roofline figure stays defined on K1 at the generate_limbs boundary: the SAME pipeline -- same
@@ -590,6 +593,7 @@ def main():
                         'effective_GBps': round(a.batch * K1F_BYTES_PER_IMAGE * (2 if a.flip else 1) * (a.size * a.size) / (640 * 640) /
                                                 (float(np.mean(stage_us['k1f_fused_limbs'])) * 1e-6) / 1e9, 1)}}
                if 'k1f_fused_limbs' in stage_us else {}),
+            'engine': engine_info,
             'rccl': group,
             'host_us_per_step': None if host_us is None else round(host_us, 1),   # host time to enqueue one step (8 ranks share one host)
             'numa': numa,

@@ -8,7 +8,8 @@ What this file adds to the eager module is the shape the hardware wants:
     per CU, pre-tiled weights), the band-resident og_conv_band_* (K split inside a workgroup, no slabs) for 10x10 / 5x5, the
     split-K kernel og_conv2d_* / og_conv2d_proj_* for the stride-2 / projection layers at 20x20 and whatever the band kernel does
     not serve, og_stem7x7_* for the stem, og_conv1x1_heads_* for the heads;
-    a shape none of them serves falls back to torch's convolution + one og_bias_act_* pass;
+    a shape none of them serves RAISES (InferenceEngine(strict=True), the default on the 16-bit GPU engines); with strict=False it
+    runs on torch's convolution + one og_bias_act_* pass and is listed in engine.torch_conv_calls;
   * the hourglass merges (nearest x2 upsample + add) on the epilogue of the convolution below them where that kernel is the
     tiled one, else one og_upsample2_add_* pass;
   * only the decoded stack's heads are evaluated (decoder/factory.py:60-63 reads feat_stage only), all of them as one
@@ -23,8 +24,8 @@ train / eval flag and device stay as they are.
 
 Environment switches (read at import; the measured-best value is the default): OG_CONV_TILED (7: bit 0 / 1 / 2 = 3x3 stride 1 /
 3x3 stride 2 / 1x1 layers on the tiled kernels), OG_CONV_UP2 (1: merges on the producing convolution's epilogue),
-OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (1: capture order at the forks of
-depth >= 1), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024: the
+OG_ENGINE_BRANCHES (1) and OG_ENGINE_BRANCH_MAX_DEPTH (4): the up1 forks, OG_ENGINE_TRUNK_FIRST (2: capture order at the forks of
+depth >= 2), OG_ENGINE_DEEP_SHARED (3: the inner up1 branches in fork order on one stream), OG_CONV_BAND_MAX_PIXELS (1024: the
 band-resident kernel for 10x10 / 5x5), OG_ENGINE_WHATIF (timing diagnosis, wrong results).  The experiments that lost their A/B (branch delay, shared side stream, stream priorities, ...) are described in
 EXPERIMENTS.md and no longer exist as switches.
 """
@@ -123,9 +124,29 @@ class _Issuer(threading.local):
     branch = 0
     build_device = None   # device the folded weights of the engine under construction go to
     ws = None             # the issuing engine's scratch buffers (None: a bare _Conv call outside an engine -> the module's _conv_ws)
+    eng = None            # the InferenceEngine whose forward is being issued (strict mode, torch_conv_calls)
+    names = None          # id(conv module) -> qualified name, while an engine's layers are being built
 
 
 _issuer = _Issuer()
+
+
+def _torch_conv(name, x, weight, stride=1, padding=0):
+    """The ONLY place the engine reaches torch's convolution (MIOpen on the GPU).  The fp32 / CPU checking path lives here; on a
+    16-bit GPU engine it means "a shape none of the hand-written kernels serves": counted in `engine.torch_conv_calls` and, in
+    strict mode (the default there), refused with the layer and shape -- the flip-test engine ran three layers on MIOpen through
+    rounds 1-5 without anybody noticing (models/hourglass_104.py:16-30,50-79 is what must run on our kernels)."""
+    eng = _issuer.eng
+    if eng is not None and eng.fused:
+        what = (f'{name}: {tuple(weight.shape[2:])} conv {weight.shape[1]} -> {weight.shape[0]}, stride {tuple(stride) if not isinstance(stride, int) else stride}, '
+                f'input {tuple(x.shape)} {str(x.dtype).replace("torch.", "")}')
+        eng.torch_conv_calls.append(what)
+        if eng.strict:
+            raise _lib.OgError(f'InferenceEngine(strict=True): no hand-written kernel serves {what}; it would run on torch / MIOpen '
+                               '(pass strict=False to allow and count it in engine.torch_conv_calls)')
+    return F.conv2d(x, weight, None, stride, padding)
+
+
 _warm_streams = {}
 _n_engines = 0
 
@@ -149,6 +170,7 @@ class _Conv:
 
     def __init__(self, conv, bn, relu, dtype, fused):
         w, b = _fold(conv, bn)
+        self.name = (_issuer.names or {}).get(id(conv), type(conv).__name__)
         self.w = w.to(dtype).contiguous(memory_format=torch.channels_last)
         self.b32 = b.float().contiguous()
         self.b = b.to(dtype)
@@ -166,7 +188,7 @@ class _Conv:
         fake = self._whatif_skipped(x)
         if fake is not None:
             return fake
-        return F.conv2d(x, self.w, None, self.stride, self.pad)
+        return _torch_conv(self.name, x, self.w, self.stride, self.pad)
 
     def _whatif_skipped(self, x):
         """OG_ENGINE_WHATIF=<classes> (diagnostic, WRONG RESULTS): layers of the named classes produce an uninitialised
@@ -577,6 +599,7 @@ class _Layers:
         self.stage = stage
         # the caller's module is only read: weights are folded from it onto the engine's device (no .to(), no .eval())
         _issuer.build_device = device
+        _issuer.names = {id(m): n for n, m in model.named_modules()}
         dev_model = model
         self.pre = [_Conv(net.pre[0].conv, net.pre[0].bn, True, dtype, fused), _Residual(net.pre[1], dtype, fused)]
         self.kps = [_Level(net.kps[s], dtype, fused) for s in range(self.stage + 1)]
@@ -620,6 +643,7 @@ class _Layers:
             self.heads_w = w.contiguous(memory_format=torch.channels_last)
             self.heads_b = b.contiguous()
         _issuer.build_device = None
+        _issuer.names = None
 
 
 _layer_cache = {}       # key -> (weak reference to the module, _Layers); at most _LAYER_CACHE_MAX entries, oldest dropped first
@@ -661,7 +685,7 @@ class InferenceEngine:
     rounding error) or torch.float32 (plain torch ops: the checking path)."""
 
     def __init__(self, model, batch, height, width, dtype=torch.float16, device='cuda:0', feat_stage=-1,
-                 use_graph=True, like=None):
+                 use_graph=True, like=None, strict=None):
         assert height % 128 == 0 and width % 128 == 0, 'Hourglass-104 needs multiples of max_stride=128'
         global _n_engines
         self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
@@ -674,6 +698,11 @@ class InferenceEngine:
         assert isinstance(model.basenet.pre[0], ConvBlock) and isinstance(model.basenet.pre[1], Residual)
         # hand-written HIP kernels on the GPU 16-bit paths (bf16, or fp16 = the reference's apex-O2 arithmetic)
         self.fused = (self.device.type == 'cuda' and dtype in (torch.bfloat16, torch.float16))
+        # strict (default on the 16-bit GPU engines; OG_ENGINE_STRICT=0 for the A/B switches that route layers to torch on purpose):
+        # a convolution none of the hand-written kernels serves raises OgError naming the layer instead of running on MIOpen;
+        # torch_conv_calls lists every such layer met since the engine was made (warm-up passes, capture and eager forwards)
+        self.strict = (self.fused and os.environ.get('OG_ENGINE_STRICT', '1') != '0') if strict is None else bool(strict)
+        self.torch_conv_calls = []
         # folded / tiled / packed weights do not depend on the input shape: engines of one (model state, dtype, device, stage)
         # share them (evaluate.run_images builds one engine per input shape, --fixed-height: one per width)
         # like = an engine the caller built for this very module a moment ago (evaluate.run_images: one per shape and lane): its
@@ -695,7 +724,13 @@ class InferenceEngine:
             self._capture()
 
     def _forward(self, images):
-        _issuer.engine, _issuer.ws = self._id, self._ws
+        _issuer.engine, _issuer.ws, _issuer.eng = self._id, self._ws, self
+        try:
+            return self._forward_impl(images)
+        finally:
+            _issuer.eng = None
+
+    def _forward_impl(self, images):
         if self.stem_w is not None:   # fused stem: fp32 NCHW images -> conv 7x7 s2 + BN + ReLU -> bf16 NHWC
             lib = _lib.load()
             images = images.float().contiguous()
@@ -747,7 +782,7 @@ class InferenceEngine:
             return tuple(outs)
         if self.heads_w is not None:
             lib = _lib.load()
-            y = F.conv2d(feat, self.heads_w)
+            y = _torch_conv('heads', feat, self.heads_w)
             n, cc, h, w = y.shape
             outs, c0 = [], 0
             for ch in self.head_channels:

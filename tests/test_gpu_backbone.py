@@ -569,6 +569,43 @@ def test_engine_replays_are_bit_identical(dev, shape):
         assert all(torch.equal(a, b) for a, b in zip(first, out))
 
 
+@pytest.mark.parametrize("shape", [(8, 640, 640), (16, 640, 640), (24, 640, 640), (1, 640, 384), (1, 640, 512), (1, 640, 896), (1, 128, 128)])
+def test_engine_runs_no_torch_convolution(dev, shape):
+    """EVERY convolution of the forward (models/hourglass_104.py:16-30,50-79,271-298) runs on a hand-written kernel: bs8 (configs[1]),
+    the flip-test batch (configs[2]: 16 images), 24 images, and batch 1 at three --fixed-height widths + the smallest input.  strict
+    is the default, so a fallback would already raise; torch_conv_calls is the counter a caller with strict=False would read."""
+    model = _bench_model(5, dev)
+    for dtype in (torch.float16, torch.bfloat16):
+        eng = models.InferenceEngine(model, *shape, device=dev, dtype=dtype)
+        assert eng.strict and eng.torch_conv_calls == []
+        eng.forward_raw(torch.randn(shape[0], 3, shape[1], shape[2], device=dev))
+        assert eng.torch_conv_calls == []
+        del eng
+        torch.cuda.empty_cache()
+
+
+def test_engine_strict_refuses_a_torch_convolution(dev, monkeypatch):
+    """A layer no hand-written kernel serves raises OgError naming the layer and its shape (here: the tiled kernels switched off, so
+    the 3x3 layers of the large levels have nowhere to go); strict=False runs it on torch and lists it."""
+    from offsetguided_amd import _lib
+    from offsetguided_amd.models import engine as E
+    model = _bench_model(5, dev)
+    monkeypatch.setattr(E, 'CONV_TILED', 0)
+    monkeypatch.setattr(E, 'CONV_SPLITK_LAST_RESORT', 0)
+    with pytest.raises(_lib.OgError, match=r'strict=True.*basenet\.pre\.1\.conv1.*\(3, 3\) conv 128 -> 256'):
+        models.InferenceEngine(model, 2, 256, 256, device=dev, use_graph=False)(torch.randn(2, 3, 256, 256, device=dev))
+    eng = models.InferenceEngine(model, 2, 256, 256, device=dev, use_graph=False, strict=False)
+    x = torch.randn(2, 3, 256, 256, device=dev)
+    with torch.no_grad():
+        ref = model(x)
+    _check_heads(ref, eng(x), torch.float16, 'strict=False on torch convolutions')
+    assert len(eng.torch_conv_calls) > 10 and any('basenet.pre.1.conv1' in c for c in eng.torch_conv_calls)
+    # the fp32 checking engine is torch by design: never strict, nothing counted
+    e32 = models.InferenceEngine(model, 2, 256, 256, device=dev, dtype=torch.float32, use_graph=False)
+    e32(x)
+    assert not e32.strict and e32.torch_conv_calls == []
+
+
 def test_engine_bench_shape_matches_eager(dev):
     """THE benchmarked configuration -- bs8 640x640 through the HIP-graph engine, bench_init weights (heads un-shrunk) -- vs the
     eager fp32 module at that shape (models/networks.py:189-194), both arithmetics."""
