@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = os.environ.get("OG_REFERENCE", "/root/reference")
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("OG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # OG_GOLDEN_OUT: regenerate into a scratch directory
 
 import oracle  # noqa: E402
 from offsetguided_amd import synth  # noqa: E402
