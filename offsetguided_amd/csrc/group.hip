@@ -51,9 +51,12 @@ constexpr int kScoreThreads = 256;         // threads that score the rows at the
 
 #ifdef OG_K3_STAMPS
 __device__ unsigned long long g_k3_stamps[16];
-#define K3_STAMP_INIT unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+__device__ unsigned long long g_k3_wall[64 * 2];   // [workgroup][entry, exit] on the 100 MHz wall clock (s_memrealtime)
+#define K3_STAMP_INIT unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    if (threadIdx.x == 0 && blockIdx.x < 64) g_k3_wall[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime()
 #define K3_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[i] += t_ - t_prev_; t_prev_ = t_; } while (0)
-#define K3_STAMP_DUMP do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) g_k3_stamps[i_] = acc_[i_]; } while (0)
+#define K3_STAMP_DUMP do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) g_k3_stamps[i_] = acc_[i_]; \
+    if (threadIdx.x == 0 && blockIdx.x < 64) g_k3_wall[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define K3_STAMP_INIT do { } while (0)
 #define K3_STAMP(i) do { } while (0)
@@ -552,4 +555,5 @@ OG_API int og_greedy_group_f32(const float *limbs, int N, int L, int k, const in
 
 #ifdef OG_K3_STAMPS   // tuning harness (tools/k3_stamps.py): cycle counts per phase of image 0's workgroup
 OG_API void og_k3_debug_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k3_stamps), sizeof(g_k3_stamps)); }
+OG_API void og_k3_wall_stamps(void *host_out) { (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k3_wall), sizeof(g_k3_wall)); }
 #endif

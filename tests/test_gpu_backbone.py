@@ -586,22 +586,23 @@ def test_engine_runs_no_torch_convolution(dev, shape):
 
 def test_engine_strict_refuses_a_torch_convolution(dev, monkeypatch):
     """A layer no hand-written kernel serves raises OgError naming the layer and its shape (here: the tiled kernels switched off, so
-    the 3x3 layers of the large levels have nowhere to go); strict=False runs it on torch and lists it."""
+    the 1x1 junction layers and the large 3x3 layers have nowhere to go); strict=False runs them on torch and lists them."""
     from offsetguided_amd import _lib
     from offsetguided_amd.models import engine as E
     model = _bench_model(5, dev)
     monkeypatch.setattr(E, 'CONV_TILED', 0)
     monkeypatch.setattr(E, 'CONV_SPLITK_LAST_RESORT', 0)
-    with pytest.raises(_lib.OgError, match=r'strict=True.*basenet\.pre\.1\.conv1.*\(3, 3\) conv 128 -> 256'):
-        models.InferenceEngine(model, 2, 256, 256, device=dev, use_graph=False)(torch.randn(2, 3, 256, 256, device=dev))
-    eng = models.InferenceEngine(model, 2, 256, 256, device=dev, use_graph=False, strict=False)
-    x = torch.randn(2, 3, 256, 256, device=dev)
+    with pytest.raises(_lib.OgError, match=r'strict=True\): no hand-written kernel serves basenet\.[\w.]+: \(\d, \d\) conv \d+ -> \d+, stride .*input \(3, \d+, \d+, \d+\) float16'):
+        models.InferenceEngine(model, 3, 256, 256, device=dev, use_graph=False)(torch.randn(3, 3, 256, 256, device=dev))
+    eng = models.InferenceEngine(model, 3, 256, 256, device=dev, use_graph=False, strict=False)
+    x = torch.randn(3, 3, 256, 256, device=dev)
     with torch.no_grad():
         ref = model(x)
     _check_heads(ref, eng(x), torch.float16, 'strict=False on torch convolutions')
-    assert len(eng.torch_conv_calls) > 10 and any('basenet.pre.1.conv1' in c for c in eng.torch_conv_calls)
+    assert len(eng.torch_conv_calls) > 10 and any('basenet.cnvs_.0.0: (1, 1) conv 256 -> 256' in c for c in eng.torch_conv_calls)
+    assert any('(3, 3) conv' in c for c in eng.torch_conv_calls)
     # the fp32 checking engine is torch by design: never strict, nothing counted
-    e32 = models.InferenceEngine(model, 2, 256, 256, device=dev, dtype=torch.float32, use_graph=False)
+    e32 = models.InferenceEngine(model, 3, 256, 256, device=dev, dtype=torch.float32, use_graph=False)
     e32(x)
     assert not e32.strict and e32.torch_conv_calls == []
 
