@@ -135,6 +135,25 @@ def k1_traffic(kernels):
     return None, None
 
 
+def k1f_counters():
+    """Counter figures of the PRODUCTION decoder kernel (band_topk_kernel<..., fused>) from the newest profiles/r*_k1f_pmc_summary.json
+    (tools/r06_run1.sh: rocprofv3 --pmc passes over tools/k1_bench.py --forms fused --bench-inputs, tools/k1f_pmc_summary.py), or {}."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_k1f_pmc_summary.json')), reverse=True):
+        try:
+            per = json.load(open(f))['per_kernel']
+            band = next(v for k, v in per.items() if k.startswith('band_topk_kernel'))
+            merge = next(v for k, v in per.items() if k.startswith('merge_collect_kernel'))
+            return {'valu_issue_frac': band['valu_issue_frac'], 'valu_issue_frac_note': 'band kernel: 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
+                    'waves_per_simd': band.get('wave_occupancy_per_simd'),
+                    'bytes': int(band['hbm_read_bytes'] + band['hbm_write_bytes'] + merge['hbm_read_bytes'] + merge['hbm_write_bytes']),
+                    'bytes_note': 'HBM bytes per launch from FETCH_SIZE (x2, gfx950) + WRITE_SIZE, band + merge kernels',
+                    'counters_source': os.path.relpath(f, ROOT)}
+        except (KeyError, ValueError, OSError, StopIteration):
+            return {}
+    return {}
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -410,6 +429,9 @@ def main():
     # running on torch / MIOpen); the counter is what a strict=False caller would read
     engine_info = {'strict': all(e.strict for e in pipe.engines), 'torch_conv_calls': sum(len(e.torch_conv_calls) for e in pipe.engines)}
     per_rank = sharding.gather_to_rank0([round(a.batch * a.steps / elapsed_rank, 2)])   # control plane only
+    # HBM footprint of a rank after the headline region (weights + L engines' activations and graphs + decoder workspaces + inputs): an
+    # 8-rank launch's memory is known in advance
+    per_rank_hbm = sharding.gather_to_rank0([int(torch.cuda.max_memory_allocated(dev))])
     # The production decoder is K1-fused (PostProcess.fused_upsample): no hi-res tensor, no HBM-streaming K1 in the
     # headline region.  The roofline figure stays defined on K1 at the generate_limbs boundary: the SAME pipeline -- same
     # engine, same inputs, same steps, every rank -- runs a second timed region in its roofline benchmark mode (K1a materialises the
@@ -422,6 +444,13 @@ def main():
         for pr in pipe.procs:
             pr.fused_upsample = True
 
+    # what a latency-sensitive caller (--inflight 1, one batch at a time) sees of the PRODUCTION decoder: K1-fused + K3 by their HIP events
+    # in a serial region of the same pipeline (with two batches in flight the same launches share the CUs with the other batch's
+    # convolutions: stage_us of the headline region; DESIGN 4 "The decoder beside the other batch")
+    serial_stage = None
+    if not a.no_extras and a.inflight > 1 and 'k1f_fused_limbs' in stage_us:
+        _, _, _, serial_stage = pipe.timed_region(a.steps, a.warmup, serial=True)
+
     def timed(fn, n):
         torch.cuda.synchronize(dev)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -433,6 +462,10 @@ def main():
         return s.elapsed_time(e) / n  # ms
 
     extras = {}
+    if serial_stage is not None:
+        k1f_1, k3_1 = float(np.mean(serial_stage['k1f_fused_limbs'])), float(np.mean(serial_stage['k3_group']))
+        extras['decoder_ms_per_img_inflight1'] = round((k1f_1 + k3_1) * 1e-3 / a.batch, 4)
+        extras['decoder_us_per_batch_inflight1'] = {'k1f_fused_limbs': round(k1f_1, 2), 'k3_group': round(k3_1, 2)}
     if not a.no_extras:
         # ---- decoder-only and backbone-only timings (outside the headline region) ----
         fixed = [[([None, m[0]], [[], []], [[], []]), ([None, m[1]], [[], []], [[], []])] for m in maps]
@@ -569,6 +602,7 @@ def main():
                        'control_plane': 'gloo (ranks share one device: test aid)' if share else 'rccl',
                        'decoder_input': 'head outputs + synthetic GT-like maps'},
             'per_rank_images_per_sec': per_rank,
+            'per_rank_hbm_bytes': per_rank_hbm,
             'poses_last_batch': [int(len(x)) for x in poses],
             'stage_us': {k: round(float(np.mean(v)), 2) for k, v in stage_us.items()},
             'roofline': {'kernel': 'K1 at the generate_limbs boundary = og_generate_limbs_f32: band_topk_kernel + '
@@ -587,11 +621,12 @@ def main():
                             {'region': {'images_per_sec': round(imgs / roof_elapsed, 2), 'ms_per_step': round(roof_elapsed / a.steps * 1e3, 3),
                                         'stage_us': {k: round(float(np.mean(v)), 2) for k, v in roof_stage.items()}}})},
             **({'k1f': {'kernel': 'K1-fused (production) = og_generate_limbs_fused_f32: band_topk_kernel<fused> (x4 bicubic + NMS + top-k from '
-                                  'the stride-4 maps) + merge_collect_kernel<fused>; VALU-bound, no roofline claim (SURVEY 8d: effective GB/s only)',
+                                  'the stride-4 maps) + merge_collect_kernel<fused>; instruction-issue bound (valu_issue_frac from the PMC passes), no HBM roofline claim (SURVEY 8d)',
                         'us_per_launch': round(float(np.mean(stage_us['k1f_fused_limbs'])), 2),
                         'lowres_bytes_per_launch': int(a.batch * K1F_BYTES_PER_IMAGE * (2 if a.flip else 1) * (a.size * a.size) / (640 * 640)),
                         'effective_GBps': round(a.batch * K1F_BYTES_PER_IMAGE * (2 if a.flip else 1) * (a.size * a.size) / (640 * 640) /
-                                                (float(np.mean(stage_us['k1f_fused_limbs'])) * 1e-6) / 1e9, 1)}}
+                                                (float(np.mean(stage_us['k1f_fused_limbs'])) * 1e-6) / 1e9, 1),
+                        **k1f_counters()}}
                if 'k1f_fused_limbs' in stage_us else {}),
             'engine': engine_info,
             'rccl': group,
@@ -649,14 +684,18 @@ def harness_block(a, model, dev, n_batches=24, warm=6):
                 marks['t0' if b == warm else 't1'] = time.perf_counter()
             imgs = [base[(b + i) % len(base)] for i in range(a.batch)]
             yield imgs, [None] * a.batch, [{'image_id': b * a.batch + i} for i in range(a.batch)]
-    results, ids = evaluate.run_images(args, loader(), model=model)
+    stats = {}
+    results, ids = evaluate.run_images(args, loader(), model=model, stats=stats)
     torch.cuda.synchronize(dev)
     dt = marks['t1'] - marks['t0']
     assert len(ids) == (n_batches + warm + 1) * a.batch
     return {'value': round(n_batches * a.batch / dt, 2), 'unit': 'images/sec', 'batches': n_batches,
             'ms_per_batch': round(dt / n_batches * 1e3, 3),
+            # host time to queue one batch (input chain + forward + decoder; no wait in it) over the timed batches
+            'host_us_per_step': round(1e6 * float(np.mean(stats['host_enqueue_s'][warm:warm + n_batches])), 1),
+            'engine': {'strict': True, 'engines_built': stats.get('engines_built'), 'torch_conv_calls': stats.get('torch_conv_calls')},
             'input': f'{a.batch} raw (h, w, 3) uint8 RGB host images per batch, eight COCO-like sizes (333x500 ... 640x640), pageable memory',
-            'stages': 'EvalPreprocess (pinned staging + one H2D copy + og_rescale_pad_normalize_u8 per image) -> InferenceEngine -> '
+            'stages': 'EvalPreprocess (pinned staging + one H2D copy + ONE og_rescale_pad_normalize_batch_u8 launch per batch) -> InferenceEngine -> '
                       'PostProcess.submit -> annotations_inverse + COCO result dicts (evaluate.run_images, reference evaluate.py:125-300)',
             'note': 'head outputs of the random-init network (no synthetic maps added): the decoder sees few candidates here'}
 

@@ -258,6 +258,14 @@ int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, int new_
                                 int corner_pad, const float *mean3, const float *std3, const float *fill3, float *out,
                                 int *ltrb, void *stream);
 
+/* The same chain for a whole batch in ONE launch (evaluate.py:157-182 collates the images of a batch before the network sees
+ * them): `raw` = the batch's uint8 images packed back to back in HBM; offsets (host long[n]) = byte offset of image i;
+ * hw4 (host int[4 n]) = (h, w, new_h, new_w) of image i; out fp32 (n,3,target_h,target_w); ltrb (host int[4 n] or NULL).
+ * Bit-identical to n calls of og_rescale_pad_normalize_u8. */
+int og_rescale_pad_normalize_batch_u8(const unsigned char *raw, const long *offsets, const int *hw4, int n, int target_h,
+                                      int target_w, int corner_pad, const float *mean3, const float *std3, const float *fill3,
+                                      float *out, int *ltrb, void *stream);
+
 /* ---- network stem: convolution(7, 3, 128, stride=2) + BN + ReLU  models/hourglass_104.py:283, :16-30 ----
  * images (N,3,H,W) fp32 (H, W multiples of 32) -> out (N,H/2,W/2,128) bf16 NHWC, input conversion and epilogue fused.
  * w_packed bf16 [128][7 kernel rows][8 taps][4 channels] (tap 7 and channel 3 zero) = the BN-folded weight

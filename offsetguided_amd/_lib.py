@@ -54,6 +54,7 @@ SIGNATURES = {
     "og_resize_cubic_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "og_shrink_mask_miss_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "og_rescale_pad_normalize_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "og_rescale_pad_normalize_batch_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "og_stem7x7_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "og_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "og_conv3x3_workspace_bytes": (_sz, [_l, _i, _i]),

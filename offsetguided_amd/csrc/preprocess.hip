@@ -129,11 +129,10 @@ __device__ __forceinline__ void resized_px_lds(const unsigned char *img, int lw,
 // at a fifth of the engine's rate.)  Footprints beyond kPrepLds bytes (scale factors above ~4) take the direct path.
 constexpr int kPrepTW = 64, kPrepTH = 4, kPrepLds = 24 * 1024;
 
-__global__ void __launch_bounds__(256)
-rescale_pad_normalize_kernel(const unsigned char *__restrict__ src, int h, int w, int nh, int nw, double sy, double sx, int left,
-                             int top, int TH, int TW, PrepArgs a, float *__restrict__ out, int tiles_x, int use_lds)
+__device__ __forceinline__ void
+rescale_pad_normalize_tile(unsigned char *img, const unsigned char *__restrict__ src, int h, int w, int nh, int nw, double sy, double sx,
+                           int left, int top, int TH, int TW, const PrepArgs &a, float *__restrict__ out, int tiles_x, int use_lds)
 {
-    __shared__ unsigned char img[kPrepLds];
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const int X = tile_x * kPrepTW + (threadIdx.x & 63), Y = tile_y * kPrepTH + (threadIdx.x >> 6);
     const int x = X - left, y = Y - top;
@@ -168,6 +167,38 @@ rescale_pad_normalize_kernel(const unsigned char *__restrict__ src, int h, int w
     const size_t i = (size_t)Y * TW + X;
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[(size_t)c * TH * TW + i] = (v[c] / 255.f - a.mean[c]) / a.stdv[c];   // ToTensor, Normalize
+}
+
+__global__ void __launch_bounds__(256)
+rescale_pad_normalize_kernel(const unsigned char *__restrict__ src, int h, int w, int nh, int nw, double sy, double sx, int left,
+                             int top, int TH, int TW, PrepArgs a, float *__restrict__ out, int tiles_x, int use_lds)
+{
+    __shared__ unsigned char img[kPrepLds];
+    rescale_pad_normalize_tile(img, src, h, w, nh, nw, sy, sx, left, top, TH, TW, a, out, tiles_x, use_lds);
+}
+
+// A whole batch in ONE launch (evaluate.py:157-182 hands the network a batch; the harness used to launch once per image):
+// blockIdx.y = image, its geometry from a by-value descriptor table in the kernel arguments (no device-side descriptor upload).
+constexpr int kPrepBatchMax = 64;
+struct PrepBatch {
+    long off[kPrepBatchMax];                      // byte offset of the image's (h, w, 3) pixels in the packed uint8 buffer
+    int h[kPrepBatchMax], w[kPrepBatchMax], nh[kPrepBatchMax], nw[kPrepBatchMax];
+};
+
+__global__ void __launch_bounds__(256)
+rescale_pad_normalize_batch_kernel(const unsigned char *__restrict__ raw, PrepBatch b, int corner_pad, int TH, int TW, PrepArgs a,
+                                   float *__restrict__ out, int tiles_x)
+{
+    __shared__ unsigned char img[kPrepLds];
+    const int n = blockIdx.y;
+    const int h = b.h[n], w = b.w[n], nh = b.nh[n], nw = b.nw[n];
+    // the same expressions as og_rescale_pad_normalize_u8 evaluates on the host: identical scales, paddings and LDS decision
+    const double sy = (double)h / nh, sx = (double)w / nw;
+    const int left = corner_pad ? 0 : (int)((TW - nw) / 2.0), top = corner_pad ? 0 : (int)((TH - nh) / 2.0);
+    const long fw = (long)(kPrepTW * sx) + 8, fh = (long)(kPrepTH * sy) + 8;
+    const int use_lds = fw * fh * 3 <= kPrepLds;
+    rescale_pad_normalize_tile(img, raw + b.off[n], h, w, nh, nw, sy, sx, left, top, TH, TW, a, out + (size_t)n * 3 * TH * TW, tiles_x,
+                               use_lds);
 }
 
 }  // namespace
@@ -222,5 +253,40 @@ OG_API int og_rescale_pad_normalize_u8(const unsigned char *img, int h, int w, i
     hipLaunchKernelGGL(rescale_pad_normalize_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, (hipStream_t)stream, img,
                        h, w, new_h, new_w, sy, sx, left, top, target_h, target_w, a, out, tiles_x, use_lds);
     OG_LAUNCH_CHECK(name);
+    return OG_OK;
+}
+
+OG_API int og_rescale_pad_normalize_batch_u8(const unsigned char *raw, const long *offsets, const int *hw4, int n, int target_h,
+                                             int target_w, int corner_pad, const float *mean3, const float *std3, const float *fill3,
+                                             float *out, int *ltrb, void *stream)
+{
+    const char *name = "og_rescale_pad_normalize_batch_u8";
+    OG_REQUIRE(raw && offsets && hw4 && mean3 && std3 && fill3 && out, OG_EINVAL, "%s: null pointer", name);
+    OG_REQUIRE(n > 0 && target_h > 0 && target_w > 0, OG_EINVAL, "%s: bad shape", name);
+    PrepArgs a;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; a.fill[c] = fill3[c]; }
+    for (int i = 0; i < n; ++i) {
+        const int h = hw4[i * 4], w = hw4[i * 4 + 1], new_h = hw4[i * 4 + 2], new_w = hw4[i * 4 + 3];
+        OG_REQUIRE(h > 0 && w > 0 && new_h > 0 && new_w > 0 && (long)h * w < (1l << 28) && offsets[i] >= 0, OG_EINVAL,
+                   "%s: image %d: bad shape", name, i);
+        OG_REQUIRE(target_h >= new_h && target_w >= new_w, OG_EINVAL, "%s: image %d: the rescaled image must fit the target", name, i);
+        if (ltrb) {
+            const int left = corner_pad ? 0 : (int)((target_w - new_w) / 2.0), top = corner_pad ? 0 : (int)((target_h - new_h) / 2.0);
+            ltrb[i * 4] = left; ltrb[i * 4 + 1] = top; ltrb[i * 4 + 2] = target_w - new_w - left; ltrb[i * 4 + 3] = target_h - new_h - top;
+        }
+    }
+    const int tiles_x = (target_w + kPrepTW - 1) / kPrepTW, tiles_y = (target_h + kPrepTH - 1) / kPrepTH;
+    for (int first = 0; first < n; first += kPrepBatchMax) {          // at most kPrepBatchMax descriptors ride in one launch's arguments
+        const int m = n - first < kPrepBatchMax ? n - first : kPrepBatchMax;
+        PrepBatch b;
+        for (int i = 0; i < kPrepBatchMax; ++i) {
+            const int j = first + (i < m ? i : 0);
+            b.off[i] = offsets[j]; b.h[i] = hw4[j * 4]; b.w[i] = hw4[j * 4 + 1]; b.nh[i] = hw4[j * 4 + 2]; b.nw[i] = hw4[j * 4 + 3];
+        }
+        hipLaunchKernelGGL(rescale_pad_normalize_batch_kernel, dim3((unsigned)(tiles_x * tiles_y), (unsigned)m), dim3(256), 0,
+                           (hipStream_t)stream, raw, b, corner_pad, target_h, target_w, a, out + (size_t)first * 3 * target_h * target_w,
+                           tiles_x);
+        OG_LAUNCH_CHECK(name);
+    }
     return OG_OK;
 }

@@ -122,8 +122,10 @@ ENGINE_CACHE = 8     # input shapes run_images keeps engines for (--fixed-height
 IN_FLIGHT = 2
 
 
-def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
-    """The hot loop of evaluate.py:207-298.  Returns (result_keypoints, result_image_ids)."""
+def run_images(args, data_loader=None, model=None, n_synthetic_batches=4, stats=None):
+    """The hot loop of evaluate.py:207-298.  Returns (result_keypoints, result_image_ids).
+    stats: an optional dict that receives `host_enqueue_s` (per batch: host time to queue the input chain, the forward and the decoder --
+    no wait in it), `engines_built` and `torch_conv_calls` (0: every engine is strict, models/engine.py)."""
     if not torch.cuda.is_available():
         raise RuntimeError('run_images needs a HIP device (offsetguided_amd has no CPU path)')
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -186,6 +188,7 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
 
     try:
         for batch_idx, ((images, _, metas), packed) in enumerate(ahead(data_loader)):
+            t_host = time.perf_counter()
             if packed is not None:
                 # raw (h, w, 3) uint8 RGB images of any size: the input chain of evaluate.py:157-168 runs on the device
                 # (RescaleLongAbsolute + CenterPad, or with --fixed-height RescaleHighAbsolute + RightDownPad of :150-156, then
@@ -212,6 +215,9 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                                                feat_stage=args.feat_stage, like=first_engine[0]), -len(lanes), None]
                 first_engine[0] = first_engine[0] or slot[0]      # the module's weights do not change inside one call
                 of_shape.append(slot)
+                if stats is not None:
+                    stats['engines_built'] = stats.get('engines_built', 0) + 1
+                    stats.setdefault('_engines', []).append(slot[0])
             cur = torch.cuda.current_stream(dev)
             if lanes[lane] is not cur:
                 lanes[lane].wait_stream(cur)                 # the input chain (H2D copy, rescale / pad / normalize, flip) ran on `cur`
@@ -224,6 +230,8 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
                 slot[1], slot[2] = batch_idx, torch.cuda.Event()
                 slot[2].record(lanes[lane])
             pending.append(handle)
+            if stats is not None:
+                stats.setdefault('host_enqueue_s', []).append(time.perf_counter() - t_host)
             while len(pending) > len(lanes):                 # the oldest batch: its poses are on the host by now (or soon)
                 collect(pending.popleft())
             if batch_idx % args.print_freq == 0:
@@ -243,6 +251,8 @@ def run_images(args, data_loader=None, model=None, n_synthetic_batches=4):
         # call holding pinned staging buffers, and a pack still queued must not write one while the caller handles the error
         if packer[0] is not None:
             packer[0].shutdown(wait=True, cancel_futures=True)
+        if stats is not None:
+            stats['torch_conv_calls'] = sum(len(e.torch_conv_calls) for e in stats.pop('_engines', []))
     return result_keypoints, result_image_ids
 
 

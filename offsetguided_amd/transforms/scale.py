@@ -4,8 +4,8 @@ the device.
 `rescale_size` and `rescale_meta` restate the reference's bookkeeping (target size from the long edge; x/y scale factors
 (w' - 1) / (w - 1), keypoint scales * sqrt(sx * sy); meta offset / scale / valid_area updates, transforms/scale.py:33-71).
 `EvalPreprocess` is the chain NormalizeAnnotations' meta -> RescaleLongAbsolute -> CenterPad -> ToTensor -> Normalize: the
-uint8 image goes to the device through a pinned staging buffer and ONE kernel (og_rescale_pad_normalize_u8) writes its
-slot of the fp32 batch tensor.  The interpolation is OpenCV's published INTER_CUBIC algorithm for 8-bit images; it is
+uint8 images of a batch go to the device through a pinned staging buffer with one copy and ONE launch
+(og_rescale_pad_normalize_batch_u8) writes the fp32 batch tensor.  The interpolation is OpenCV's published INTER_CUBIC algorithm for 8-bit images; it is
 pinned to the CPU restatement in oracle/, parity with cv2 itself is unpinned (cv2 is not available offline)."""
 import ctypes as C
 import math
@@ -142,16 +142,22 @@ class EvalPreprocess:
             stage[1] = torch.cuda.Event()
             stage[1].record(self.copy_stream)
             out = torch.empty((len(images), 3, PH, PW), dtype=torch.float32, device=self.device)
+            # ONE launch for the batch (og_rescale_pad_normalize_batch_u8: blockIdx.y = image, the geometry table rides in the
+            # kernel arguments); a launch per image cost the host 0.3 ms per batch and the device eight ramps and tails
+            n = len(sizes)
+            offs, hw4, ltrb = (C.c_long * n)(), (C.c_int * (4 * n))(), (C.c_int * (4 * n))()
+            for i, (h, w) in enumerate(sizes):
+                offs[i] = o
+                hw4[4 * i:4 * i + 4] = [h, w, targets[i][1], targets[i][0]]
+                o += h * w * 3
+            _lib.check(lib.og_rescale_pad_normalize_batch_u8(_lib.ptr(dev_raw), offs, hw4, n, PH, PW, int(self.fixed_height),
+                                                             self._mean, self._std, self._fill, _lib.ptr(out), ltrb,
+                                                             _lib.stream_ptr(self.device)), lib)
             for i, (h, w) in enumerate(sizes):
                 tw, th = targets[i]
-                ltrb = (C.c_int * 4)()
-                _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(dev_raw.data_ptr() + o), h, w, th, tw, PH, PW,
-                                                           int(self.fixed_height), self._mean, self._std, self._fill,
-                                                           _lib.ptr(out[i]), ltrb, _lib.stream_ptr(self.device)), lib)
-                o += h * w * 3
                 meta, _ = rescale_meta(initial_meta(w, h, None if image_ids is None else image_ids[i]), None, w, h, tw, th)
-                meta['offset'] = meta['offset'] - np.array(ltrb[:2], np.float64)          # CenterPad, transforms/pad.py:28-31
-                meta['valid_area'][:2] += np.array(ltrb[:2], np.float64)
+                meta['offset'] = meta['offset'] - np.array(ltrb[4 * i:4 * i + 2], np.float64)          # CenterPad, transforms/pad.py:28-31
+                meta['valid_area'][:2] += np.array(ltrb[4 * i:4 * i + 2], np.float64)
                 meta['width_height'] = np.array([PW, PH])
                 metas.append(meta)
         cur = torch.cuda.current_stream(self.device)

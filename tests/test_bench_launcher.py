@@ -170,16 +170,26 @@ def test_more_gpus_than_devices_fails_loudly():
 
 @pytest.mark.gpu
 def test_two_rank_bench_on_the_gpu():
+    """bench.py --gpus 2 as the driver launches it for the scaling curve, on whatever this box has: two devices over RCCL, or both
+    ranks on the one device with gloo as the control plane -- with TWO batches in flight per rank (the default: four lanes, four engines
+    on a shared device).  Both ranks make progress at a similar rate, the group really has two ranks, and the line carries what an
+    8-rank launch needs to be planned: per-rank HBM footprint, host time per step, the hardware-queue setting."""
     import torch
     two = torch.cuda.device_count() >= 2
     env = _clean_env() if two else _clean_env(OG_BENCH_SHARE_DEVICE='1')
-    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
-                        '--no-extras', '--inflight', '1'],      # (one batch in flight: two ranks on one device build four engines otherwise)
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
+                        '--no-extras', '--inflight', '2'],
                        capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)
-    assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['batches_in_flight'] == 2
     assert line['config']['control_plane'] == ('rccl' if two else 'gloo (ranks share one device: test aid)')
-    assert line['value'] > 0 and len(line['per_rank_images_per_sec']) == 2
+    assert line['rccl']['world'] == 2 and len(line['rccl']['device_ids']) == 2
+    per = line['per_rank_images_per_sec']
+    assert line['value'] > 0 and len(per) == 2 and abs(per[0] - per[1]) <= 0.15 * max(per), per
     # whole-job value = all ranks' images over the slowest rank's time
-    assert abs(line['value'] - 2 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3
+    assert abs(line['value'] - 2 * 8 * 6 / (line['ms_per_step'] * 6e-3)) / line['value'] < 1e-3
+    assert line['engine'] == {'strict': True, 'torch_conv_calls': 0}
+    hbm = line['per_rank_hbm_bytes']
+    assert len(hbm) == 2 and all(1 << 30 < b < 64 << 30 for b in hbm), hbm      # weights + two engines' activations: a few GB of the 288
+    assert line['host_us_per_step'] > 0 and line['knobs']['GPU_MAX_HW_QUEUES'] == '4'

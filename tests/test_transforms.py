@@ -126,6 +126,50 @@ def test_resize_and_fused_chain_bit_exact_vs_restatement():
         assert torch.equal(out[2], single[0])
 
 
+@pytest.mark.gpu
+def test_batched_input_chain_equals_per_image_launches():
+    """og_rescale_pad_normalize_batch_u8 (one launch per batch, evaluate.py:157-182) == og_rescale_pad_normalize_u8 per image, bit for
+    bit: mixed sizes incl. a 4.7x reduction (the tile footprint exceeds the LDS image: direct path) and an enlargement, both
+    paddings, and more images than one launch's descriptor table holds (64)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    import ctypes as C
+    from offsetguided_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    mean, std, fill = f3(data_mean), f3(data_std), f3(transforms.pad.FILL)
+    for T, fixed, sizes in ((640, False, [(427, 640), (640, 480), (3000, 2000), (97, 131), (640, 640)]),
+                            (128, False, [(31 + i, 17 + 2 * i) for i in range(70)]),
+                            (256, True, [(300, 400), (150, 200), (600, 800)])):
+        images = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+        raw = torch.from_numpy(np.concatenate([im.ravel() for im in images])).to(dev)
+        n = len(images)
+        targets = [transforms.rescale_size(w, h, T, fixed) for h, w in sizes]
+        up = lambda v: (v + 127) // 128 * 128  # noqa: E731
+        PH, PW = (up(targets[0][1]), up(targets[0][0])) if fixed else (T, T)
+        offs, hw4, ltrb = (C.c_long * n)(), (C.c_int * (4 * n))(), (C.c_int * (4 * n))()
+        o = 0
+        one = torch.empty((n, 3, PH, PW), device=dev)
+        for i, (h, w) in enumerate(sizes):
+            offs[i] = o
+            hw4[4 * i:4 * i + 4] = [h, w, targets[i][1], targets[i][0]]
+            l4 = (C.c_int * 4)()
+            _lib.check(lib.og_rescale_pad_normalize_u8(C.c_void_p(raw.data_ptr() + o), h, w, targets[i][1], targets[i][0], PH, PW, int(fixed),
+                                                       mean, std, fill, _lib.ptr(one[i]), l4, _lib.stream_ptr(dev)), lib)
+            o += h * w * 3
+            one_ltrb = list(l4) if i == 0 else one_ltrb + list(l4)
+        got = torch.full((n, 3, PH, PW), float('nan'), device=dev)
+        _lib.check(lib.og_rescale_pad_normalize_batch_u8(_lib.ptr(raw), offs, hw4, n, PH, PW, int(fixed), mean, std, fill, _lib.ptr(got),
+                                                         ltrb, _lib.stream_ptr(dev)), lib)
+        assert torch.equal(got, one) and list(ltrb) == one_ltrb, (T, fixed)
+    hw_bad = (C.c_int * 4)(10, 10, 700, 700)
+    rc = lib.og_rescale_pad_normalize_batch_u8(_lib.ptr(raw), (C.c_long * 1)(0), hw_bad, 1, 640, 640, 0, mean, std, fill, _lib.ptr(got), None,
+                                               _lib.stream_ptr(dev))
+    assert rc == _lib.OG_EINVAL and b'must fit the target' in lib.og_last_error()
+
+
 def _mask_cases():
     rng = np.random.default_rng(5)
     m = np.full((3, 128, 192), 255, np.uint8)
