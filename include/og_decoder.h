@@ -210,8 +210,9 @@ int og_flip_cat_f32(const float *hm, const float *off, int N, int C, int L, int 
                     float *hm_out, float *off_out, void *stream);
 
 /* ---- backbone epilogues (bf16, channels-last / NHWC activations of the inference engine) ----
- * The convolutions stay on MIOpen; these fuse what PyTorch would launch as separate elementwise
- * kernels after each of them.
+ * Stand-alone epilogue / layout passes.  In the engine every convolution carries its epilogue itself (og_conv*_ below);
+ * og_bias_act_* is what remains for a convolution that torch ran (InferenceEngine(strict=False) only), og_upsample2_add_* the
+ * hourglass merge at the levels whose last convolution is not the tiled kernel.
  *
  * og_bias_act_bf16: x (pixels, channels) bf16, in place:  x = act(x + bias[c] (+ skip))
  *   = convolution.forward models/hourglass_104.py:26-30 (BN folded into bias, ReLU) and
@@ -340,8 +341,9 @@ int og_conv_band_f16(const void *x, const void *w_packed, const float *bias, con
  *     with k in its natural order (for og_conv1x1_tiled_* / og_conv1x1_heads_*).
  *   og_conv3x3_tiled_bf16: x (N,H,W,Cin), skip / out (N,H,W,Cout), bias fp32[Cout]; replaces convolution.forward
  *     models/hourglass_104.py:26-30 / residual.forward :70-79 (BN folded) like og_conv3x3_bf16. */
-/* Optional hint for the NEXT og_conv3x3_tiled_* / og_conv3x3_tiled_up2_* / og_conv_band_* launch issued by this host thread (taken and
- * cleared by it): [w_next, w_next + bytes) = the packed weights of the layer that will run AFTER that launch.  The launch's
+/* Optional hint for the NEXT convolution launch issued by this host thread -- og_conv3x3_tiled_* / og_conv3x3_tiled_up2_* /
+ * og_conv3x3s2_tiled_* / og_conv_band_* / og_conv2d_* / og_conv2d_proj_* / og_conv3x3_* (every launch of the five takes and clears it;
+ * the 1x1 kernels og_conv1x1_* and the stem do not look at it): [w_next, w_next + bytes) = the packed weights of the layer that will run AFTER that launch.  The launch's
  * workgroups touch those lines at entry (values unused), so that the next layer of a dependent chain -- the 20x20 / 10x10 / 5x5 levels,
  * whose layers are bound by the latency of first-touch weight reads -- finds its weights in the memory-side cache instead of HBM.
  * Purely a performance hint: results do not depend on it; NULL / 0 clears it. */

@@ -1,8 +1,8 @@
 // Backbone epilogues for the bf16 channels-last (NHWC) inference engine.
 //
-// MIOpen runs the convolutions (MFMA igemm); PyTorch would then launch separate elementwise
-// kernels for the (BN-folded) bias add, the residual add and the ReLU -- ~390 launches and two
-// to three full passes over every activation per forward.  These kernels do the whole epilogue of
+// Stand-alone passes.  Since round 3 every convolution of the engine carries bias + residual + ReLU in its own epilogue
+// (conv3x3*.inc / conv_band.hip); what is left here: og_bias_act_* behind a convolution that torch ran (InferenceEngine(strict=False)
+// only), og_upsample2_add_* for the hourglass merges of the 20x20 / 10x10 levels, the layout kernels.  They do the epilogue of
 //   convolution.forward  (models/hourglass_104.py:26-30):  relu(conv + b)
 //   residual.forward     (models/hourglass_104.py:70-79):  relu(conv2 + b2 + skip)
 //   kp_module.forward    (models/hourglass_104.py:183-190): up1 + nearest_x2(low3)

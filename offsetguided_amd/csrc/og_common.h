@@ -38,7 +38,10 @@ OgWarm og_take_warm_hint();
 
 // Device side: thread `gtid` of the launch touches line `gtid` of the region (a launch has more threads than the region has lines: one
 // load per thread at most).  The loads are the OLDEST vector-memory operations of their wave: every counted wait behind them covers
-// them; the value is kept alive until the end of the kernel by og_warm_sink.
+// them; the value is kept alive until the end of the kernel by og_warm_sink.  (A plain load: the compiler is free to sink it towards
+// that use.  It does not -- in every kernel that calls this the load is the first vector-memory instruction of the ISA, 21 lines below
+// the entry (checked in round 6: hipcc --offload-device-only -S) -- and the counted vmcnt waits of the tiled kernels would be off by one
+// if it ever moved between their DMA issues: re-check after a compiler change.)
 __device__ __forceinline__ unsigned og_warm_touch(const OgWarm &w, unsigned gtid)
 {
     unsigned v = 0;

@@ -239,9 +239,17 @@ class PostProcess(torch.nn.Module):
             n_limbs = offs.shape[1] // 2
             keep = [1 if l in self.limbs_flips[1] else 0 for l in range(n_limbs)]
             if self.fused_upsample:
-                return self.limb_collect.generate_limbs_fused_flip(hmps, offs, self.keypoints_flips, self.limbs_flips[0], keep)
-            hmps_hr = upsample4_flip(hmps, self.keypoints_flips)
-            return self.limb_collect.generate_limbs_flip(hmps_hr, offs, self.limbs_flips[0], keep)
+                try:
+                    return self.limb_collect.generate_limbs_fused_flip(hmps, offs, self.keypoints_flips, self.limbs_flips[0], keep)
+                except _lib.OgError as e:
+                    # merge + pairing of the folded form keeps a plane's lists in LDS: beyond k ~ 226 at 640 x 640 (half that for inputs
+                    # twice as tall) it does not fit and the C side says OG_EUNSUPPORTED.  The unfolded route below (flip_augment as its own
+                    # pass, then K1-fused with its collect-kernel fallback) serves the same request with the same results.
+                    if f'(code {_lib.OG_EUNSUPPORTED})' not in str(e):
+                        raise
+            else:
+                hmps_hr = upsample4_flip(hmps, self.keypoints_flips)
+                return self.limb_collect.generate_limbs_flip(hmps_hr, offs, self.limbs_flips[0], keep)
         if flip_test:
             hmps, jomps, offs, scmps, vector_nd = self.flip_augment(hmps, jomps, offs, scmps, cat_flip_offs, vector_nd)
         if scored_off:

@@ -93,7 +93,13 @@ def poses_to_results(image_poses, image_meta, result_keypoints, result_image_ids
         n_kp = sub.shape[1]
         flags = ((sub[:, :, 0] > 0) | (sub[:, :, 1] > 0)).astype(int).tolist()
         trip = np.concatenate((sub[:, :, :2], np.zeros(sub.shape[:2] + (1,))), axis=2).reshape(len(sub), 3 * n_kp).tolist()
-        scores = (np.cumsum(sub[:, :, 2], axis=1)[:, -1] / n_kp).tolist()        # cumsum adds left to right, as sum() does
+        # the reference's sum(v) / len(v) (evaluate.py:252) as explicit left-to-right float64 adds, column by column -- what Python's sum()
+        # does up to 3.11 (from 3.12 on sum() of floats is Neumaier-compensated: the last ulp of a score may then differ from a reference
+        # run under that interpreter; this box and the reference's pins run 3.10 / 3.7)
+        total = sub[:, 0, 2].copy()
+        for j in range(1, n_kp):
+            total += sub[:, j, 2]
+        scores = (total / n_kp).tolist()
         for triples, flag, score in zip(trip, flags, scores):
             triples[2::3] = flag
             result_keypoints.append({'image_id': image_id, 'category_id': 1, 'keypoints': triples, 'score': score})

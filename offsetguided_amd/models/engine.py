@@ -651,15 +651,34 @@ _LAYER_CACHE_MAX = 2
 
 
 def _model_signature(model):
-    """Identity of a module's CURRENT weights: storage address, version counter, shape and sum of every parameter and buffer --
-    an optimizer step, load_state_dict, .to() or a write through .data changes it, so a cached bundle never serves stale weights
-    (0.15-0.2 s for Hourglass-104 on the host, a few ms on the device: callers that build several engines for one unchanged
-    module pass the first one's bundle on, InferenceEngine(like=...))."""
-    sig = 0
+    """Identity of a module's CURRENT weights: storage address, version counter, shape and a position-weighted checksum of the BIT
+    PATTERNS of every parameter and buffer -- an optimizer step, load_state_dict, .to() or a write through .data changes it, so a
+    cached bundle never serves stale weights.  Bit patterns, not values: a NaN parameter hashes like any other number (a float sum
+    made the signature differ on every call), and a value-preserving permutation of a tensor's entries is seen.  The checksums of all
+    tensors are computed where the tensors live and come back in ONE transfer (one host <-> device sync per device instead of one per
+    parameter).  What no checksum can promise: a deliberate collision; callers that edit weights through .data and want certainty call
+    invalidate_engine_cache().  (Callers that build several engines for one unchanged module pass the first one's bundle on,
+    InferenceEngine(like=...).)"""
+    meta, sums = [], {}
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
-            sig = hash((sig, t.data_ptr(), t._version, tuple(t.shape), float(t.double().sum()) if t.numel() else 0.0))
-    return sig
+            meta.append((t.data_ptr(), t._version, tuple(t.shape), str(t.dtype), str(t.device)))
+            if not t.numel():
+                continue
+            d = t.detach().contiguous()
+            bits = d.view(torch.int32) if d.element_size() == 4 else (d.view(torch.int16) if d.element_size() == 2 else
+                                                                      d.view(torch.int64) if d.element_size() == 8 else d.view(torch.int8))
+            bits = bits.reshape(-1).to(torch.int64)
+            w = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)      # odd weights: position matters
+            sums.setdefault(d.device, []).append((bits * w).sum())                                  # (wraps modulo 2^64: fine for a checksum)
+    digest = tuple(tuple(torch.stack(v).tolist()) for _, v in sorted(sums.items(), key=lambda kv: str(kv[0])))
+    return hash((tuple(meta), digest))
+
+
+def invalidate_engine_cache():
+    """Forget every cached weight bundle: the next InferenceEngine folds the module's weights afresh (after edits through .data that a
+    caller does not want to leave to the checksum)."""
+    _layer_cache.clear()
 
 
 def _shared_layers(model, dtype, device, stage, fused):

@@ -373,6 +373,26 @@ def test_flip_fold_equals_flip_merge(dev, shape, headnet, topk):
     assert_poses_match(ref, poses_fold[:2], SCORE_TOL)
 
 
+def test_folded_flip_beyond_the_lds_limit_takes_the_unfolded_route(dev):
+    """--topk beyond what the folded K1-fused form's merge + pairing stage holds in LDS (about k = 226 at 640 x 640): the C side answers
+    OG_EUNSUPPORTED and generate_limbs falls back to flip_augment as its own pass + K1-fused -- the same limbs, bit for bit, as with the
+    fold switched off, and below the limit the fold is taken."""
+    n, size, k = 1, 640, 240
+    hm, off = synth.synth_batch(77, n, size, size, flip=True)
+    t_hm, t_off = torch.from_numpy(hm).to(dev), torch.from_numpy(off).to(dev)
+    feats = [([None, t_hm], [[], []], [[], []]), ([None, t_off], [[], []], [[], []])]
+    proc = processor(n, topk=k)
+    assert proc.fold_flip and proc.fused_upsample
+    kp_perm, (limb_perm, reserve) = proc.keypoints_flips, proc.limbs_flips
+    keep = [1 if l in reserve else 0 for l in range(len(limb_perm))]
+    with pytest.raises(_lib.OgError, match=r'code -4'):
+        proc.limb_collect.generate_limbs_fused_flip(t_hm, t_off, kp_perm, limb_perm, keep)
+    got = proc.generate_limbs(feats, flip_test=True).clone()
+    proc.fold_flip = False
+    ref = proc.generate_limbs(feats, flip_test=True)
+    assert got.shape == (n, 19, k, 13) and torch.equal(got, ref)
+
+
 def test_fused_flip_fold_few_peaks(dev):
     """The folded flip in K1-fused where a plane has FEWER than k positive peaks: the merge stage then fills the list with the lowest
     zero-output indices, evaluating the x4 bicubic of the MERGED source at single points (merge_plane's zero-fill path with the

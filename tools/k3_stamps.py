@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['OG_DECODER_LIB'] = os.path.abspath(sys.argv[1])
+if __name__ == '__main__':
+    os.environ['OG_DECODER_LIB'] = os.path.abspath(sys.argv[1])      # (before offsetguided_amd._lib is imported: it reads the variable then)
 from offsetguided_amd import _lib, decoder, models, synth  # noqa: E402
 import argparse  # noqa: E402
 
