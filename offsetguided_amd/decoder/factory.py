@@ -145,6 +145,8 @@ class PostProcess(torch.nn.Module):
         # submit(): grouping (one workgroup per image, latency-bound) and the pose D2H copy run on their own stream, so
         # the caller's next launches (the following batch's backbone) do not queue behind them
         self.group_on_side_stream = True   # (an attribute, no longer an environment switch: measured best since round 2)
+        if 'OG_GROUP_SIDE_STREAM' in os.environ:
+            LOG.warning('OG_GROUP_SIDE_STREAM is no longer read (removed in round 5): set PostProcess.group_on_side_stream instead')
         self._side = {}
         self._pinned = {}   # (poses shape, meta shape) -> [_HostSlot]: pinned landing areas of submit()
         LOG.info('decode stage %d features (heatmap head %d, offset head %d), %s heatmap resize, '

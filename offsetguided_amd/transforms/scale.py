@@ -131,7 +131,7 @@ class EvalPreprocess:
         metas, o = [], 0
         # The whole input chain runs on the COPY stream, behind the H2D copy it depends on: the caller's stream is busy with the
         # previous batch (the host runs a batch ahead), and eight small launches queued there sat between that batch's decoder and this
-        # batch's backbone (tools/harness_gaps.py: 185 us between the heads kernel and the next stem).  The caller's stream only waits
+        # batch's backbone (a kernel trace of round 5: 185 us between the heads kernel and the next stem).  The caller's stream only waits
         # for the finished tensor.  (Neutral on bench.py's harness figure, 1 267 vs 1 271 img/s: the host waits 4.7 of every 6.2 ms for
         # the previous batch, tools/harness_host_times.py -- the pitch is the device's.)
         with torch.cuda.stream(self.copy_stream):
