@@ -129,6 +129,7 @@ class _Issuer(threading.local):
 
 
 _issuer = _Issuer()
+_live_engines = __import__('weakref').WeakValueDictionary()      # engine id -> InferenceEngine, while it exists
 
 
 def _torch_conv(name, x, weight, stride=1, padding=0):
@@ -535,8 +536,12 @@ class _Level:
                     side = _issuer.deep_side[1]
                 else:
                     side = _lib.new_stream(x.device)
-                if len(self._side) >= 32:       # engines come and go (evaluate.run_images keeps 8 shapes x 2 lanes per model): forget the oldest
-                    _lib.release_stream(self._side.pop(next(iter(self._side))))     # (its graph was captured long ago)
+                if len(self._side) >= 32:       # engines come and go (evaluate.run_images keeps 8 shapes x 2 lanes per model): forget the
+                    # oldest entry whose engine no longer exists (the oldest entry may belong to a live engine that runs
+                    # eagerly and still needs its stream; with 32 live engines the table simply grows)
+                    dead = next((k for k in self._side if k[1] not in _live_engines), None)
+                    if dead is not None:
+                        _lib.release_stream(self._side.pop(dead))
                 self._side[key] = side
             box = {}
             trunk_first = bool(TRUNK_FIRST) and self.depth >= TRUNK_FIRST
@@ -709,6 +714,7 @@ class InferenceEngine:
         global _n_engines
         self._id = _n_engines            # scratch (split-K slabs, tickets) is per engine: two engines may be in flight
         _n_engines += 1
+        _live_engines[self._id] = self
         self.device = torch.device(device)
         self.dtype = dtype
         self.shape = (batch, 3, height, width)
